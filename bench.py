@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- parties/s of one n-party PVW `encrypt` on MI355X, with the roofline of the
+dominant kernel (mac_rows) and the CPU restatement timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c1|c4shard]
+
+A "step" is one full encrypt (sample r/e1/e2 from a seed, NTT, c1 = A r + e1,
+c2 = B r + e2 + m g; src/crypto/encryption.rs:105-214) over synthetic A-hat / B-hat that are
+already resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): the
+parties are sharded over the ranks (weak scaling: every rank holds the per-GPU party count),
+A-hat is broadcast once over RCCL at load time, and there is no collective on the data path.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+CONFIGS = {
+    # name: (n per GPU, k, l, limbs, description)
+    "c1": (16, 256, 8, 17, "BASELINE configs[0]: n=16, k=256, l=8, 1037-bit q (plumbing)"),
+    "c2": (1024, 256, 8, 17, "BASELINE configs[1]: n=1024, k=256, l=8, 1037-bit q"),
+    "c3": (4096, 256, 8, 17, "BASELINE configs[2] / north-star target: n=4096, k=256, l=8, 1037-bit q (17 limbs)"),
+    "c4shard": (2048, 512, 16, 34, "BASELINE configs[3] per-GPU shard: n=16384/8, k=512, l=16, 2074-bit q"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SEED_A, SEED_B, SEED_ENC = bytes([0xA]) * 32, bytes([0xB]) * 32, bytes([0x2A]) * 32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import pvw_model as M
+    import pvw_rs_amd as P
+    from pvw_rs_amd import _ffi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
+        print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available() or not P.device_available():
+        print("bench.py needs a gfx950 GPU: the PVW hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n_per, k, l, L, desc = CONFIGS[args.config]
+    n_total = n_per * world
+    moduli = M.bench_moduli(L)
+    lo, hi = rank * n_per, (rank + 1) * n_per
+    clo, chi = k * rank // world, k * (rank + 1) // world
+    params = (P.PvwParametersBuilder().set_parties(n_total).set_dimension(k).set_l(l).set_moduli(moduli)
+              .set_secret_variance(0.5).set_error_bounds_u32(100, 200).set_device(local_rank)
+              .set_shard(lo, hi, clo, chi).build())
+    h = params._h
+    lib = _ffi.lib()
+
+    # ---- residency: A-hat (generated on rank 0, broadcast ONCE over RCCL/xGMI), B-hat shard ----
+    if world > 1:
+        import torch.distributed as dist
+        a_dev = torch.empty((k, k, L, l), dtype=torch.int64, device=dev)
+        if rank == 0:
+            p0 = (P.PvwParametersBuilder().set_parties(n_total).set_dimension(k).set_l(l).set_moduli(moduli)
+                  .set_device(local_rank).build())
+            a_host = P.PvwCrs.new_deterministic(p0, SEED_A).matrix(P.REPR_NTT)
+            a_dev.copy_(torch.from_numpy(a_host.view(np.int64)))
+            del p0
+        dist.broadcast(a_dev, src=0)
+        torch.cuda.synchronize()
+        P.api._check(lib.pvw_load_crs_device(h, C.c_void_p(a_dev.data_ptr()), P.REPR_NTT,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        del a_dev
+        crs = P.PvwCrs(params)
+    else:
+        crs = P.PvwCrs.new_deterministic(params, SEED_A)
+    gpk = P.GlobalPublicKey.new(crs)
+    gpk.fill_uniform(SEED_B)
+
+    scalars = torch.tensor([(i * 1000 + 1) % (1 << 32) for i in range(n_total)], dtype=torch.int64, device=dev)
+    c1 = torch.zeros((chi - clo, L, l), dtype=torch.int64, device=dev)
+    c2 = torch.zeros((n_per, L, l), dtype=torch.int64, device=dev)
+    rnd = _ffi.pvw_randomness_t()
+    rnd.mode = _ffi.RND_SEED
+    C.memmove(rnd.seed, SEED_ENC, 32)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        rc = lib.pvw_encrypt_device(h, C.c_void_p(scalars.data_ptr()), n_total, C.byref(rnd),
+                                    C.c_void_p(c1.data_ptr()), C.c_void_p(c2.data_ptr()), P.REPR_NTT, stream)
+        if rc != 0:
+            raise RuntimeError(_ffi.last_error())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: HIP events around every mac_rows launch --------------
+    params.set_profiling(True)
+    params.reset_profiling()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    kt = {name: params.kernel_time(name) for name in ("mac_rows", "sample", "prep")}
+    params.set_profiling(False)
+    mac_ms, mac_launches = kt["mac_rows"]
+    mac_avg_s = mac_ms / max(mac_launches, 1) * 1e-3
+    rows_a = chi - clo
+    # algorithmic bytes of one mac_rows launch: B-hat + A-hat reads, c2 + c1 writes, r-hat read
+    alg_bytes = 8 * L * l * (n_per * k + rows_a * k + n_per + rows_a + k)
+    achieved = alg_bytes / mac_avg_s / 1e9 if mac_avg_s > 0 else 0.0
+
+    out = {
+        "metric": "parties/s for n-party encrypt (pvw::crypto::encrypt); achieved HBM GB/s vs peak",
+        "value": value, "unit": "parties/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": desc, "parties_per_gpu": n_per, "parties_total": n_total, "k": k, "l": l,
+                   "rns_limbs": L, "q_bits": int(params.q_total().bit_length()), "randomness": "seed (ChaCha8), on device",
+                   "sharding": f"party-sharded x{world}, A-hat broadcast once, no data-path collective"},
+        "roofline": {"bound": "hbm", "kernel": "mac_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": mac_avg_s * 1e6,
+                     "launches_timed": mac_launches},
+        "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},
+    }
+
+    # ---- CPU baseline: the C restatement (oracle/) on this box's host cores, rank 0, N=1 only ----
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import pvw_oracle as O
+        n_cpu = min(n_per, 4096)
+        orc = O.Oracle(moduli, l)
+        a_hat = crs.matrix(P.REPR_NTT)
+        b_hat = gpk.matrix(0, n_cpu, P.REPR_NTT)
+        g_hat = params.gadget_polynomial(P.REPR_NTT)
+        r = O.sample_cbd(SEED_ENC, M.DOM_R, 0, k, l, 0.5)
+        e1 = O.sample_uniform(SEED_ENC, M.DOM_E1, 0, k, l, 100)
+        e2 = O.sample_uniform(SEED_ENC, M.DOM_E2, 0, n_cpu, l, 200)
+        sc = np.array([(i * 1000 + 1) % (1 << 32) for i in range(n_cpu)], dtype=np.uint64)
+        c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, sc, r, e1, e2, serial_c1=True)   # also warms up
+        # the run above doubles as a full-size parity check of this very bench workload
+        same = bool(np.array_equal(c1o.view(np.int64), c1.cpu().numpy()) and
+                    np.array_equal(c2o.view(np.int64), c2.cpu().numpy()[:n_cpu]))
+        reps, t_cpu = 0, 0.0
+        while t_cpu < args.cpu_seconds and reps < 200:
+            t1 = time.perf_counter()
+            orc.encrypt(a_hat, b_hat, g_hat, sc, r, e1, e2, serial_c1=True)
+            t_cpu += time.perf_counter() - t1
+            reps += 1
+        out["cpu_baseline"] = {
+            "value": n_cpu * reps / t_cpu, "unit": "parties/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"{reps} x the same encrypt (n={n_cpu}, k={k}, l={l}, {L} limbs, explicit r/e1/e2) with oracle/pvw_oracle.c, "
+                      f"OpenMP over parties, c1 loop serial as in crs.rs:188; {t_cpu:.1f} s of CPU work",
+            "bit_exact_vs_gpu": same,
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

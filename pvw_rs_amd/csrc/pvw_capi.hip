@@ -1,0 +1,1246 @@
+// pvw_capi.hip -- C ABI (include/pvw_hip.h) over the gfx950 kernels: context, parameter
+// arithmetic, device residency of A-hat / B-hat, encrypt / decrypt orchestration, decode.
+//
+// The product path has no CPU fallback: every bulk polynomial operation runs in a HIP
+// kernel and every device entry point fails with PVW_ERR_INTERNAL when no gfx950 device
+// is usable.  Host-side code here is what the reference also does on the host with
+// num-bigint: parameter set-up (src/params/parameters.rs:117-195), the f64 correctness
+// gate (:510-551) and the integer gadget decode (src/crypto/decryption.rs:10-247).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pvw_hip.h"
+#include "pvw_arith.h"
+#include "pvw_bignum.h"
+#include "pvw_chacha.h"
+#include "pvw_kernels.h"
+
+using namespace pvw;
+
+// ------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+static int32_t fail(int32_t code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define PVW_HIP(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(PVW_ERR_INTERNAL, std::string("HIP error: ") + hipGetErrorString(e_) +  \
+                                        " at " #expr);                                     \
+  } while (0)
+#define PVW_TRY(expr)              \
+  do {                             \
+    int32_t rc_ = (expr);          \
+    if (rc_ != PVW_OK) return rc_; \
+  } while (0)
+
+// ------------------------------------------------------------------------ number theory (host)
+static bool is_prime_u64(u64 n) {
+  if (n < 2) return false;
+  static const u64 small[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+  for (u64 p : small)
+    if (n % p == 0) return n == p;
+  u64 d = n - 1;
+  int s = 0;
+  while ((d & 1) == 0) { d >>= 1; ++s; }
+  for (u64 a : small) {
+    u128 x = 1, b = a % n;
+    for (u64 e = d; e; e >>= 1) {
+      if (e & 1) x = x * b % n;
+      b = b * b % n;
+    }
+    if (x == 1 || x == n - 1) continue;
+    bool comp = true;
+    for (int i = 1; i < s; ++i) {
+      x = x * x % n;
+      if (x == n - 1) { comp = false; break; }
+    }
+    if (comp) return false;
+  }
+  return true;
+}
+static u32 ilog2(u32 x) { u32 b = 0; while ((1u << b) < x) ++b; return b; }
+
+// smallest primitive `order`-th root of unity mod q: this build's deterministic psi
+static u64 min_primitive_root(const Mod& m, u32 order) {
+  u64 e = (m.q - 1) / order, w = 0;
+  for (u64 g = 2;; ++g) {
+    w = powmod(g, e, m);
+    if (powmod(w, order / 2, m) == m.q - 1) break;
+  }
+  u64 best = w, cur = w, w2 = mulmod(w, w, m);
+  for (u32 i = 1; i < order / 2; ++i) {
+    cur = mulmod(cur, w2, m);
+    if (cur < best) best = cur;
+  }
+  return best;
+}
+// runtime-l host NTT (table building, gadget): natural in, bit-reversed out
+static void host_ntt_forward(u64* a, u32 l, const u64* tw, const Mod& m) {
+  u32 step = l;
+  for (u32 mm = 1; mm < l; mm <<= 1) {
+    step >>= 1;
+    for (u32 i = 0; i < mm; ++i) {
+      u64 w = tw[mm + i];
+      for (u32 j = 2 * i * step; j < 2 * i * step + step; ++j) {
+        u64 u = a[j], v = mulmod(a[j + step], w, m);
+        a[j] = addmod(u, v, m.q);
+        a[j + step] = submod(u, v, m.q);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------ context
+struct ProfRec {
+  std::string name;
+  hipEvent_t a, b;
+};
+struct Workspace {
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  i64* small = nullptr;      // [(2k + nB)][l] sampled / uploaded small coefficients
+  u64* rhat = nullptr;       // [L][k][l]
+  u64* scalars = nullptr;    // [n]
+  u64* c1 = nullptr;         // [rowsA][L][l]
+  u64* c2 = nullptr;         // [rowsB][L][l]
+  void* scratch = nullptr;   // growable staging
+  size_t scratch_bytes = 0;
+};
+
+struct pvw_ctx {
+  u32 n, k, l, L;
+  std::vector<u64> moduli, psi;
+  float variance;
+  u64 b1, b2;
+  int device;
+  u32 party_lo, party_hi, c1_lo, c1_hi;
+  BigInt Q, halfQ, delta, delta_pow;
+  std::vector<BigInt> crt_qi;    // Q / q_i
+  std::vector<u64> crt_inv;      // (Q/q_i)^-1 mod q_i
+  std::vector<Mod> mods;
+  std::vector<u64> tw, itw, linv, ghat, gpow;
+  bool roots_locked = false;
+
+  // device state
+  bool dev_ready = false;
+  void* d_tables = nullptr;
+  DevTables dt{};
+  u64* dA = nullptr;  // tiled A-hat rows [c1_lo, c1_hi)
+  u64* dB = nullptr;  // tiled B-hat rows [party_lo, party_hi)
+  bool crs_loaded = false;
+  u32 num_keys = 0;
+  hipStream_t stream = nullptr;
+
+  std::mutex mu;
+  std::vector<Workspace*> pool;
+  std::map<void*, Workspace*> async_ws;
+
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  std::map<std::string, std::pair<double, uint64_t>> prof_acc;
+
+  u32 rowsA() const { return c1_hi - c1_lo; }
+  u32 rowsB() const { return party_hi - party_lo; }
+  u32 R() const { return 128 / l; }
+  size_t poly() const { return (size_t)L * l; }
+  size_t tiled_words(u32 rows) const { return (size_t)((rows + R() - 1) / R()) * L * k * 128; }
+};
+
+struct ProfScope {
+  pvw_ctx* c;
+  hipStream_t s;
+  ProfRec rec;
+  bool on;
+  ProfScope(pvw_ctx* c_, const char* name, hipStream_t s_) : c(c_), s(s_), on(c_->profiling) {
+    if (on) {
+      rec.name = name;
+      hipEventCreate(&rec.a);
+      hipEventCreate(&rec.b);
+      hipEventRecord(rec.a, s);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      hipEventRecord(rec.b, s);
+      std::lock_guard<std::mutex> g(c->mu);
+      c->prof.push_back(rec);
+    }
+  }
+};
+
+static void build_tables(pvw_ctx* c) {
+  const u32 L = c->L, l = c->l, bits = ilog2(l);
+  c->tw.assign((size_t)L * l, 0);
+  c->itw.assign((size_t)L * l, 0);
+  c->linv.assign(L, 0);
+  c->gpow.assign((size_t)L * l, 0);
+  c->ghat.assign((size_t)L * l, 0);
+  for (u32 i = 0; i < L; ++i) {
+    const Mod& m = c->mods[i];
+    u64 psi = c->psi[i], ipsi = powmod(psi, m.q - 2, m);
+    for (u32 x = 0; x < l; ++x) {
+      c->tw[(size_t)i * l + x] = powmod(psi, bitrev32(x, bits), m);
+      c->itw[(size_t)i * l + x] = powmod(ipsi, bitrev32(x, bits), m);
+    }
+    c->linv[i] = powmod(l, m.q - 2, m);
+    // gadget residues D^j mod q_i (parameters.rs:288-308) and their NTT
+    u64 dm = c->delta.mod_small(m.q), p = 1;
+    for (u32 j = 0; j < l; ++j) {
+      c->gpow[(size_t)i * l + j] = p;
+      p = mulmod(p, dm, m);
+    }
+    std::vector<u64> g(c->gpow.begin() + (size_t)i * l, c->gpow.begin() + (size_t)(i + 1) * l);
+    host_ntt_forward(g.data(), l, &c->tw[(size_t)i * l], m);
+    std::copy(g.begin(), g.end(), c->ghat.begin() + (size_t)i * l);
+  }
+}
+
+static int32_t upload_tables(pvw_ctx* c) {
+  const size_t L = c->L, l = c->l;
+  const size_t bytes = L * sizeof(Mod) + 4 * L * l * 8 + L * 8;
+  if (!c->d_tables) PVW_HIP(hipMalloc(&c->d_tables, bytes));
+  char* p = (char*)c->d_tables;
+  auto put = [&](const void* src, size_t n) -> const void* {
+    const void* at = p;
+    hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+    p += n;
+    return at;
+  };
+  c->dt.mods = (const Mod*)put(c->mods.data(), L * sizeof(Mod));
+  c->dt.tw = (const u64*)put(c->tw.data(), L * l * 8);
+  c->dt.itw = (const u64*)put(c->itw.data(), L * l * 8);
+  c->dt.ghat = (const u64*)put(c->ghat.data(), L * l * 8);
+  c->dt.gpow = (const u64*)put(c->gpow.data(), L * l * 8);
+  c->dt.linv = (const u64*)put(c->linv.data(), L * 8);
+  PVW_HIP(hipDeviceSynchronize());
+  return PVW_OK;
+}
+
+static int32_t ensure_device(pvw_ctx* c) {
+  if (c->dev_ready) {
+    PVW_HIP(hipSetDevice(c->device));
+    return PVW_OK;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail(PVW_ERR_INTERNAL, "no HIP device available: the PVW hot path has no CPU fallback");
+  if (c->device < 0) {
+    int cur = 0;
+    PVW_HIP(hipGetDevice(&cur));
+    c->device = cur;
+  }
+  if (c->device >= count) return fail(PVW_ERR_INTERNAL, "device ordinal out of range");
+  PVW_HIP(hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  PVW_HIP(hipGetDeviceProperties(&prop, c->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(PVW_ERR_INTERNAL, std::string("kernels are built for gfx950 only, device is ") +
+                                      prop.gcnArchName);
+  PVW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PVW_TRY(upload_tables(c));
+  c->dev_ready = true;
+  c->roots_locked = true;
+  return PVW_OK;
+}
+
+static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
+  const size_t l = c->l, k = c->k, P = c->poly();
+  PVW_HIP(hipMalloc((void**)&w->small, (2 * k + c->rowsB()) * l * sizeof(i64) + 16));
+  PVW_HIP(hipMalloc((void**)&w->rhat, k * P * 8));
+  return PVW_OK;
+}
+static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
+  const size_t P = c->poly();
+  if (!w->scalars) PVW_HIP(hipMalloc((void**)&w->scalars, (size_t)c->n * 8 + 16));
+  if (!w->c1) PVW_HIP(hipMalloc((void**)&w->c1, (size_t)c->rowsA() * P * 8 + 16));
+  if (!w->c2) PVW_HIP(hipMalloc((void**)&w->c2, (size_t)c->rowsB() * P * 8 + 16));
+  return PVW_OK;
+}
+static int32_t ws_scratch(Workspace* w, size_t bytes) {
+  if (w->scratch_bytes >= bytes) return PVW_OK;
+  if (w->scratch) hipFree(w->scratch);
+  w->scratch = nullptr;
+  w->scratch_bytes = 0;
+  PVW_HIP(hipMalloc(&w->scratch, bytes));
+  w->scratch_bytes = bytes;
+  return PVW_OK;
+}
+static void ws_free(Workspace* w) {
+  if (!w) return;
+  hipFree(w->small);
+  hipFree(w->rhat);
+  hipFree(w->scalars);
+  hipFree(w->c1);
+  hipFree(w->c2);
+  hipFree(w->scratch);
+  if (w->own_stream && w->stream) hipStreamDestroy(w->stream);
+  delete w;
+}
+// synchronous host-buffer calls take a private workspace + stream from the pool
+static int32_t ws_acquire(pvw_ctx* c, Workspace** out) {
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->pool.empty()) {
+      *out = c->pool.back();
+      c->pool.pop_back();
+      return PVW_OK;
+    }
+  }
+  Workspace* w = new Workspace();
+  if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete w;
+    return fail(PVW_ERR_INTERNAL, "hipStreamCreate failed");
+  }
+  w->own_stream = true;
+  int32_t rc = ws_alloc(c, w);
+  if (rc != PVW_OK) { ws_free(w); return rc; }
+  *out = w;
+  return PVW_OK;
+}
+static void ws_release(pvw_ctx* c, Workspace* w) {
+  std::lock_guard<std::mutex> g(c->mu);
+  c->pool.push_back(w);
+}
+// asynchronous device-pointer calls keep one workspace per stream (stream order protects it)
+static int32_t ws_for_stream(pvw_ctx* c, hipStream_t s, Workspace** out) {
+  std::lock_guard<std::mutex> g(c->mu);
+  auto it = c->async_ws.find((void*)s);
+  if (it != c->async_ws.end()) { *out = it->second; return PVW_OK; }
+  Workspace* w = new Workspace();
+  w->stream = s;
+  int32_t rc = ws_alloc(c, w);
+  if (rc != PVW_OK) { ws_free(w); return rc; }
+  c->async_ws[(void*)s] = w;
+  *out = w;
+  return PVW_OK;
+}
+
+// ------------------------------------------------------------------------ parameters
+static int32_t validate_params(const pvw_params_t* p) {
+  if (!p) return fail(PVW_ERR_INVALID_PARAMETERS, "params is NULL");
+  if (p->n == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "n must be > 0");                 // parameters.rs:132
+  if (p->k == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "k must be > 0");                 // :135
+  if (p->l < 8 || (p->l & (p->l - 1)) != 0)                                               // :140
+    return fail(PVW_ERR_INVALID_PARAMETERS, "l must be power of 2 and >= 8 (fhe.rs Context requirement)");
+  if (p->l > 64) return fail(PVW_ERR_INVALID_PARAMETERS, "l > 64 is not supported by the gfx950 kernels");
+  if (p->num_moduli == 0 || !p->moduli) return fail(PVW_ERR_INVALID_PARAMETERS, "moduli not set");  // :129
+  for (u32 i = 0; i < p->num_moduli; ++i) {
+    u64 q = p->moduli[i];
+    char buf[96];
+    snprintf(buf, sizeof buf, "Context creation failed: modulus %#llx ", (unsigned long long)q);
+    if (q >= (1ull << 62) || q < 3) return fail(PVW_ERR_INVALID_PARAMETERS, std::string(buf) + "must be in [3, 2^62)");
+    if (!is_prime_u64(q)) return fail(PVW_ERR_INVALID_PARAMETERS, std::string(buf) + "is not prime");
+    if ((q - 1) % (2 * (u64)p->l) != 0)
+      return fail(PVW_ERR_INVALID_PARAMETERS, std::string(buf) + "is not 1 mod 2l (no NTT of size l)");
+    for (u32 j = 0; j < i; ++j)
+      if (p->moduli[j] == q) return fail(PVW_ERR_INVALID_PARAMETERS, std::string(buf) + "is repeated");
+  }
+  if (p->error_bound_1 == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "error_bound_1 must be positive");  // :172
+  if (p->error_bound_2 == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "error_bound_2 must be positive");  // :177
+  if (p->error_bound_1 >= (1ull << 62) || p->error_bound_2 >= (1ull << 62))
+    return fail(PVW_ERR_INVALID_PARAMETERS, "error bounds must be below 2^62");
+  return PVW_OK;
+}
+
+static void compute_q_delta(const u64* moduli, u32 L, u32 l, BigInt& Q, BigInt& delta, BigInt& dpow) {
+  Q = BigInt(1);
+  for (u32 i = 0; i < L; ++i) Q = Q * BigInt(moduli[i]);
+  delta = Q.nth_root(l);            // parameters.rs:156
+  dpow = delta.pow(l - 1);          // :159-163
+}
+
+static double correctness_bound(double n, double k, double l, double b1, double b2) {  // parameters.rs:510-544
+  double first = b2 * std::sqrt(n * l) * (1.0 + std::sqrt(n));
+  double second = 2.0 * b1 * k * l;
+  double third = 14.0 * b1 * std::sqrt(n * k * l);
+  return first + second + third;
+}
+
+extern "C" {
+
+int32_t pvw_last_error(char* buf, size_t len) {
+  if (!buf || len == 0) return PVW_ERR_INVALID_PARAMETERS;
+  snprintf(buf, len, "%s", g_last_error.c_str());
+  return PVW_OK;
+}
+
+int32_t pvw_device_available(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return 0;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int32_t pvw_ctx_create(const pvw_params_t* p, pvw_ctx** out) {
+  if (!out) return fail(PVW_ERR_INVALID_PARAMETERS, "out is NULL");
+  *out = nullptr;
+  PVW_TRY(validate_params(p));
+  pvw_ctx* c = new pvw_ctx();
+  c->n = p->n; c->k = p->k; c->l = p->l; c->L = p->num_moduli;
+  c->moduli.assign(p->moduli, p->moduli + p->num_moduli);
+  c->variance = p->secret_variance;
+  c->b1 = p->error_bound_1; c->b2 = p->error_bound_2;
+  c->device = p->device;
+  c->party_lo = p->party_lo; c->party_hi = p->party_hi;
+  c->c1_lo = p->c1_lo; c->c1_hi = p->c1_hi;
+  if (c->party_lo == 0 && c->party_hi == 0) c->party_hi = c->n;
+  if (c->c1_lo == 0 && c->c1_hi == 0) c->c1_hi = c->k;
+  if (c->party_lo > c->party_hi || c->party_hi > c->n || c->c1_lo > c->c1_hi || c->c1_hi > c->k) {
+    delete c;
+    return fail(PVW_ERR_INVALID_PARAMETERS, "party / c1 shard out of range");
+  }
+  compute_q_delta(c->moduli.data(), c->L, c->l, c->Q, c->delta, c->delta_pow);
+  c->halfQ = c->Q.shr(1);
+  for (u32 i = 0; i < c->L; ++i) {
+    c->mods.push_back(make_mod(c->moduli[i]));
+    c->psi.push_back(min_primitive_root(c->mods[i], 2 * c->l));
+    BigInt qi = c->Q / BigInt(c->moduli[i]);
+    c->crt_qi.push_back(qi);
+    c->crt_inv.push_back(powmod(qi.mod_small(c->moduli[i]), c->moduli[i] - 2, c->mods[i]));
+  }
+  build_tables(c);
+  *out = c;
+  return PVW_OK;
+}
+
+int32_t pvw_ctx_destroy(pvw_ctx* c) {
+  if (!c) return PVW_OK;
+  if (c->dev_ready) {
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& r : c->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (Workspace* w : c->pool) ws_free(w);
+    for (auto& kv : c->async_ws) ws_free(kv.second);
+    hipFree(c->dA);
+    hipFree(c->dB);
+    hipFree(c->d_tables);
+    if (c->stream) hipStreamDestroy(c->stream);
+  }
+  delete c;
+  return PVW_OK;
+}
+
+int32_t pvw_ctx_get_roots(const pvw_ctx* c, uint64_t* psi_out) {
+  if (!c || !psi_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  memcpy(psi_out, c->psi.data(), c->L * 8);
+  return PVW_OK;
+}
+
+int32_t pvw_ctx_set_roots(pvw_ctx* c, const uint64_t* psi) {
+  if (!c || !psi) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (c->roots_locked)
+    return fail(PVW_ERR_CONTEXT, "roots must be set before any device operation");
+  for (u32 i = 0; i < c->L; ++i)
+    if (psi[i] >= c->moduli[i] || powmod(psi[i], c->l, c->mods[i]) != c->moduli[i] - 1)
+      return fail(PVW_ERR_INVALID_PARAMETERS, "psi is not a primitive 2l-th root of unity");
+  c->psi.assign(psi, psi + c->L);
+  build_tables(c);
+  return PVW_OK;
+}
+
+static int32_t export_big(const BigInt& v, uint64_t* words, size_t cap, size_t* nwords) {
+  if (!nwords) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  *nwords = v.mag.size();
+  if (words) {
+    if (cap < v.mag.size()) return fail(PVW_ERR_INSUFFICIENT_DATA, "word buffer too small");
+    memcpy(words, v.mag.data(), v.mag.size() * 8);
+  }
+  return PVW_OK;
+}
+int32_t pvw_ctx_delta(const pvw_ctx* c, uint64_t* w, size_t cap, size_t* n) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  return export_big(c->delta, w, cap, n);
+}
+int32_t pvw_ctx_delta_power_l_minus_1(const pvw_ctx* c, uint64_t* w, size_t cap, size_t* n) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  return export_big(c->delta_pow, w, cap, n);
+}
+int32_t pvw_ctx_q_total(const pvw_ctx* c, uint64_t* w, size_t cap, size_t* n) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  return export_big(c->Q, w, cap, n);
+}
+
+int32_t pvw_ctx_gadget(const pvw_ctx* c, uint64_t* poly_out, uint32_t repr) {
+  if (!c || !poly_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  const std::vector<u64>& src = repr == PVW_REPR_NTT ? c->ghat : c->gpow;
+  memcpy(poly_out, src.data(), src.size() * 8);
+  return PVW_OK;
+}
+
+int32_t pvw_ctx_verify_correctness_condition(const pvw_ctx* c, int32_t* ok) {
+  if (!c || !ok) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  double bound = correctness_bound((double)c->n, (double)c->k, (double)c->l, (double)c->b1, (double)c->b2);
+  *ok = c->delta_pow.to_double() > bound ? 1 : 0;   // parameters.rs:547-550 (to_f64 saturates to +inf)
+  return PVW_OK;
+}
+
+int32_t pvw_suggest_error_bounds(uint32_t n, uint32_t k, uint32_t l, const uint64_t* moduli,
+                                 uint32_t num_moduli, float variance, uint32_t* b1o, uint32_t* b2o) {
+  if (!b1o || !b2o) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  pvw_params_t p{};
+  p.n = n; p.k = k; p.l = l; p.moduli = moduli; p.num_moduli = num_moduli;
+  p.secret_variance = variance; p.error_bound_1 = 1; p.error_bound_2 = 1; p.device = -1;   // parameters.rs:562-569
+  PVW_TRY(validate_params(&p));
+  BigInt Q, d, dp;
+  compute_q_delta(moduli, num_moduli, l, Q, d, dp);
+  const double dpf = dp.to_double();
+  const double nf = n, kf = k, lf = l;
+  const double c1 = 2.0 * kf * lf + 14.0 * std::sqrt(nf * kf * lf);      // :578-580
+  const double c2 = std::sqrt(nf * lf) * (1.0 + std::sqrt(nf));          // :583-585
+  static const uint32_t cand[] = {50, 100, 200, 500, 1000, 2000};
+  for (uint32_t e1 : cand)
+    for (uint32_t e2 : cand)
+      if (dpf > (double)e1 * c1 + (double)e2 * c2) { *b1o = e1; *b2o = e2; return PVW_OK; }   // :588-598
+  char buf[160];
+  snprintf(buf, sizeof buf, "Cannot find suitable error bounds for variance %g with the correctness condition", variance);
+  return fail(PVW_ERR_INVALID_PARAMETERS, buf);
+}
+
+int32_t pvw_ctx_resident_bytes(const pvw_ctx* c, uint64_t* crs, uint64_t* pk) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  if (crs) *crs = c->tiled_words(c->rowsA()) * 8;
+  if (pk) *pk = c->tiled_words(c->rowsB()) * 8;
+  return PVW_OK;
+}
+
+int32_t pvw_ctx_synchronize(pvw_ctx* c) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  PVW_TRY(ensure_device(c));
+  PVW_HIP(hipDeviceSynchronize());
+  return PVW_OK;
+}
+
+// ------------------------------------------------------------------------ profiling
+static void prof_resolve(pvw_ctx* c) {
+  hipDeviceSynchronize();
+  std::lock_guard<std::mutex> g(c->mu);
+  for (auto& r : c->prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& acc = c->prof_acc[r.name];
+      acc.first += ms;
+      acc.second += 1;
+    }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  c->prof.clear();
+}
+int32_t pvw_ctx_set_profiling(pvw_ctx* c, int32_t on) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  c->profiling = on != 0;
+  return PVW_OK;
+}
+int32_t pvw_ctx_kernel_time(pvw_ctx* c, const char* name, double* total_ms, uint64_t* launches) {
+  if (!c || !name) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (c->dev_ready) { hipSetDevice(c->device); prof_resolve(c); }
+  std::lock_guard<std::mutex> g(c->mu);
+  auto it = c->prof_acc.find(name);
+  if (total_ms) *total_ms = it == c->prof_acc.end() ? 0.0 : it->second.first;
+  if (launches) *launches = it == c->prof_acc.end() ? 0 : it->second.second;
+  return PVW_OK;
+}
+int32_t pvw_ctx_reset_profiling(pvw_ctx* c) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  if (c->dev_ready) { hipSetDevice(c->device); prof_resolve(c); }
+  std::lock_guard<std::mutex> g(c->mu);
+  c->prof_acc.clear();
+  return PVW_OK;
+}
+
+// ------------------------------------------------------------------------ CRS / public key residency
+static int32_t ensure_matrix(pvw_ctx* c, u64** M, u32 rows) {
+  if (*M || rows == 0) return PVW_OK;
+  const size_t bytes = c->tiled_words(rows) * 8;
+  PVW_HIP(hipMalloc((void**)M, bytes));
+  PVW_HIP(hipMemsetAsync(*M, 0, bytes, c->stream));   // padding rows must read as zero
+  PVW_HIP(hipStreamSynchronize(c->stream));
+  return PVW_OK;
+}
+
+// rows [lo, hi) (global numbering) of a matrix whose shard is [shard_lo, shard_hi); d_src holds
+// [hi-lo][k][L][l].  Rows outside the shard are skipped.
+static int32_t load_rows_device(pvw_ctx* c, u64* M, u32 shard_lo, u32 shard_hi, u32 lo, u32 hi,
+                                const u64* d_src, uint32_t repr, hipStream_t s) {
+  const u32 a = lo > shard_lo ? lo : shard_lo, b = hi < shard_hi ? hi : shard_hi;
+  if (a >= b) return PVW_OK;
+  const size_t rowwords = (size_t)c->k * c->poly();
+  ProfScope ps(c, "tile", s);
+  PVW_HIP(launch_tile(d_src + (size_t)(a - lo) * rowwords, M, b - a, a - shard_lo, c->k, c->L, c->l,
+                      repr == PVW_REPR_POWER, c->dt, s));
+  return PVW_OK;
+}
+// host source, staged through a bounded device buffer
+static int32_t load_rows_host(pvw_ctx* c, u64* M, u32 shard_lo, u32 shard_hi, u32 lo, u32 hi,
+                              const u64* src, uint32_t repr) {
+  const u32 a = lo > shard_lo ? lo : shard_lo, b = hi < shard_hi ? hi : shard_hi;
+  if (a >= b) return PVW_OK;
+  const size_t rowwords = (size_t)c->k * c->poly();
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  size_t chunk = ((size_t)256 << 20) / (rowwords * 8);
+  if (chunk == 0) chunk = 1;
+  int32_t rc = ws_scratch(w, (chunk < (size_t)(b - a) ? chunk : (size_t)(b - a)) * rowwords * 8);
+  for (u32 r0 = a; rc == PVW_OK && r0 < b; r0 += (u32)chunk) {
+    const u32 cnt = (b - r0) < chunk ? (b - r0) : (u32)chunk;
+    if (hipMemcpyAsync(w->scratch, src + (size_t)(r0 - lo) * rowwords, cnt * rowwords * 8,
+                       hipMemcpyHostToDevice, w->stream) != hipSuccess) {
+      rc = fail(PVW_ERR_INTERNAL, "H2D copy failed");
+      break;
+    }
+    rc = load_rows_device(c, M, shard_lo, shard_hi, r0, r0 + cnt, (const u64*)w->scratch, repr, w->stream);
+    if (rc == PVW_OK && hipStreamSynchronize(w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");
+  }
+  ws_release(c, w);
+  return rc;
+}
+static int32_t check_repr(uint32_t repr) {
+  if (repr != PVW_REPR_POWER && repr != PVW_REPR_NTT) return fail(PVW_ERR_INVALID_FORMAT, "unknown representation");
+  return PVW_OK;
+}
+
+int32_t pvw_load_crs(pvw_ctx* c, const uint64_t* a, uint32_t repr) {
+  if (!c || !a) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(repr));
+  PVW_TRY(ensure_device(c));
+  PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
+  PVW_TRY(load_rows_host(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, a, repr));
+  c->crs_loaded = true;
+  return PVW_OK;
+}
+int32_t pvw_load_crs_device(pvw_ctx* c, const uint64_t* d_a, uint32_t repr, void* stream) {
+  if (!c || !d_a) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(repr));
+  PVW_TRY(ensure_device(c));
+  PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  PVW_TRY(load_rows_device(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, d_a, repr, s));
+  c->crs_loaded = true;
+  return PVW_OK;
+}
+int32_t pvw_crs_generate(pvw_ctx* c, const uint8_t seed[32]) {
+  if (!c || !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(ensure_device(c));
+  PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
+  {
+    ProfScope ps(c, "fill_uniform", c->stream);
+    PVW_HIP(launch_fill_uniform_tiled(c->dA, make_key(seed), DOM_CRS, c->rowsA(), 0, c->c1_lo, c->k, c->L,
+                                      c->l, c->dt, c->stream));
+  }
+  PVW_HIP(hipStreamSynchronize(c->stream));
+  c->crs_loaded = true;
+  return PVW_OK;
+}
+static int32_t get_rows(pvw_ctx* c, const u64* M, u32 shard_lo, u32 shard_hi, u32 lo, u32 hi,
+                        uint64_t* dst, uint32_t repr) {
+  const u32 a = lo > shard_lo ? lo : shard_lo, b = hi < shard_hi ? hi : shard_hi;
+  if (a >= b) return PVW_OK;
+  if (!M) return fail(PVW_ERR_INVALID_PARAMETERS, "matrix not loaded");
+  const size_t rowwords = (size_t)c->k * c->poly();
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  size_t chunk = ((size_t)256 << 20) / (rowwords * 8);
+  if (chunk == 0) chunk = 1;
+  int32_t rc = ws_scratch(w, (chunk < (size_t)(b - a) ? chunk : (size_t)(b - a)) * rowwords * 8);
+  for (u32 r0 = a; rc == PVW_OK && r0 < b; r0 += (u32)chunk) {
+    const u32 cnt = (b - r0) < chunk ? (b - r0) : (u32)chunk;
+    if (launch_untile(M, (u64*)w->scratch, cnt, r0 - shard_lo, c->k, c->L, c->l, repr == PVW_REPR_POWER,
+                      c->dt, w->stream) != hipSuccess ||
+        hipMemcpyAsync(dst + (size_t)(r0 - lo) * rowwords, w->scratch, cnt * rowwords * 8,
+                       hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+        hipStreamSynchronize(w->stream) != hipSuccess)
+      rc = fail(PVW_ERR_INTERNAL, "untile / D2H failed");
+  }
+  ws_release(c, w);
+  return rc;
+}
+int32_t pvw_get_crs(pvw_ctx* c, uint64_t* a_out, uint32_t repr) {
+  if (!c || !a_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(repr));
+  PVW_TRY(ensure_device(c));
+  return get_rows(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, a_out, repr);
+}
+
+static int32_t check_party_range(const pvw_ctx* c, u32 lo, u32 hi) {
+  if (lo > hi) return fail(PVW_ERR_INVALID_PARAMETERS, "party_lo > party_hi");
+  if (hi > c->n) {                                                                 // public_key.rs:216-222
+    char buf[96];
+    snprintf(buf, sizeof buf, "Party index %u exceeds maximum %u", hi - 1, c->n - 1);
+    return fail(PVW_ERR_INVALID_PARAMETERS, buf);
+  }
+  return PVW_OK;
+}
+int32_t pvw_load_pk(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t* b, uint32_t repr) {
+  if (!c || !b) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(repr));
+  PVW_TRY(check_party_range(c, lo, hi));
+  PVW_TRY(ensure_device(c));
+  PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
+  PVW_TRY(load_rows_host(c, c->dB, c->party_lo, c->party_hi, lo, hi, b, repr));
+  if (hi > c->num_keys) c->num_keys = hi;                                          // public_key.rs:245-247
+  return PVW_OK;
+}
+int32_t pvw_load_pk_device(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t* d_b, uint32_t repr, void* stream) {
+  if (!c || !d_b) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(repr));
+  PVW_TRY(check_party_range(c, lo, hi));
+  PVW_TRY(ensure_device(c));
+  PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  PVW_TRY(load_rows_device(c, c->dB, c->party_lo, c->party_hi, lo, hi, d_b, repr, s));
+  if (hi > c->num_keys) c->num_keys = hi;
+  return PVW_OK;
+}
+int32_t pvw_pk_fill_uniform(pvw_ctx* c, const uint8_t seed[32]) {
+  if (!c || !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(ensure_device(c));
+  PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
+  {
+    ProfScope ps(c, "fill_uniform", c->stream);
+    PVW_HIP(launch_fill_uniform_tiled(c->dB, make_key(seed), DOM_PK, c->rowsB(), 0, c->party_lo, c->k, c->L,
+                                      c->l, c->dt, c->stream));
+  }
+  PVW_HIP(hipStreamSynchronize(c->stream));
+  c->num_keys = c->party_hi;
+  return PVW_OK;
+}
+int32_t pvw_get_pk(pvw_ctx* c, uint32_t lo, uint32_t hi, uint64_t* b_out, uint32_t repr) {
+  if (!c || !b_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(repr));
+  PVW_TRY(check_party_range(c, lo, hi));
+  PVW_TRY(ensure_device(c));
+  return get_rows(c, c->dB, c->party_lo, c->party_hi, lo, hi, b_out, repr);
+}
+int32_t pvw_num_public_keys(const pvw_ctx* c, uint32_t* out) {
+  if (!c || !out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  *out = c->num_keys;
+  return PVW_OK;
+}
+int32_t pvw_is_full(const pvw_ctx* c, int32_t* out) {
+  if (!c || !out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  *out = c->num_keys >= c->party_hi ? 1 : 0;                                        // public_key.rs:349-351
+  return PVW_OK;
+}
+
+// ------------------------------------------------------------------------ samplers
+static int32_t cbd_job(float variance, SampleJob& j) {
+  if (!(variance >= 0.5f && variance <= 16.0f))
+    return fail(PVW_ERR_SAMPLING, "The variance should be between 0.5 and 16");          // uniform.rs:32-34
+  j.kind = SAMPLE_CBD;
+  j.cbd_half = std::fabs(variance - 0.5f) < 1.1920929e-07f ? 1 : 0;                       // :38
+  j.cbd_v = (u32)variance;                                                                // :47
+  if (!j.cbd_half && j.cbd_v < 1)
+    return fail(PVW_ERR_SAMPLING, "non-integer variance below 1 is not supported (the reference's bit pool is empty there)");
+  j.bound = 0;
+  return PVW_OK;
+}
+
+int32_t pvw_sample_cbd(pvw_ctx* c, const uint8_t seed[32], uint32_t domain, uint32_t index0, size_t count,
+                       float variance, int64_t* out) {
+  if (!c || !seed || (!out && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  SampleJob j{}, z{};
+  PVW_TRY(cbd_job(variance, j));
+  if (count == 0) return PVW_OK;
+  PVW_TRY(ensure_device(c));
+  j.domain = domain; j.index0 = index0; j.count = (u32)count; j.out_poly0 = 0;
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  int32_t rc = ws_scratch(w, count * c->l * 8);
+  if (rc == PVW_OK) {
+    ProfScope ps(c, "sample", w->stream);
+    if (launch_sample((i64*)w->scratch, make_key(seed), c->l, j, z, z, w->stream) != hipSuccess)
+      rc = fail(PVW_ERR_INTERNAL, "sample launch failed");
+  }
+  if (rc == PVW_OK && (hipMemcpyAsync(out, w->scratch, count * c->l * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                       hipStreamSynchronize(w->stream) != hipSuccess))
+    rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  ws_release(c, w);
+  return rc;
+}
+
+int32_t pvw_sample_uniform(pvw_ctx* c, const uint8_t seed[32], uint32_t domain, uint32_t index0, size_t count,
+                           uint64_t bound, int64_t* out) {
+  if (!c || !seed || (!out && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (bound >= (1ull << 62)) return fail(PVW_ERR_SAMPLING, "bound must be below 2^62");
+  if (count == 0) return PVW_OK;
+  PVW_TRY(ensure_device(c));
+  SampleJob j{}, z{};
+  j.kind = SAMPLE_UNIFORM; j.domain = domain; j.index0 = index0; j.count = (u32)count; j.bound = bound;
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  int32_t rc = ws_scratch(w, count * c->l * 8);
+  if (rc == PVW_OK) {
+    ProfScope ps(c, "sample", w->stream);
+    if (launch_sample((i64*)w->scratch, make_key(seed), c->l, j, z, z, w->stream) != hipSuccess)
+      rc = fail(PVW_ERR_INTERNAL, "sample launch failed");
+  }
+  if (rc == PVW_OK && (hipMemcpyAsync(out, w->scratch, count * c->l * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                       hipStreamSynchronize(w->stream) != hipSuccess))
+    rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  ws_release(c, w);
+  return rc;
+}
+
+int32_t pvw_sample_gaussian(pvw_ctx* c, const uint8_t seed[32], uint32_t index0, size_t count, uint64_t bound,
+                            int64_t* out) {
+  if (!c || !seed || (!out && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (bound >= (1ull << 62)) return fail(PVW_ERR_SAMPLING, "bound must be below 2^62");
+  if (count == 0) return PVW_OK;
+  PVW_TRY(ensure_device(c));
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  int32_t rc = ws_scratch(w, count * 8);
+  if (rc == PVW_OK) {
+    ProfScope ps(c, "gaussian", w->stream);
+    if (launch_gaussian((i64*)w->scratch, make_key(seed), index0, (u32)count, bound, w->stream) != hipSuccess)
+      rc = fail(PVW_ERR_INTERNAL, "gaussian launch failed");
+  }
+  if (rc == PVW_OK && (hipMemcpyAsync(out, w->scratch, count * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                       hipStreamSynchronize(w->stream) != hipSuccess))
+    rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  ws_release(c, w);
+  return rc;
+}
+
+int32_t pvw_sample_secret_keys(const pvw_ctx* cc, const uint8_t seed[32], uint32_t party_lo, uint32_t count,
+                               int64_t* sk_out) {
+  pvw_ctx* c = const_cast<pvw_ctx*>(cc);
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  // party p, polynomial j uses stream index p*k + j
+  return pvw_sample_cbd(c, seed, PVW_DOM_SK, party_lo * c->k, (size_t)count * c->k, c->variance, sk_out);
+}
+
+// ------------------------------------------------------------------------ ring primitives on host buffers
+int32_t pvw_ntt_forward(pvw_ctx* c, uint64_t* polys, size_t count) {
+  if (!c || (!polys && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (count == 0) return PVW_OK;
+  PVW_TRY(ensure_device(c));
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  const size_t bytes = count * c->poly() * 8;
+  int32_t rc = ws_scratch(w, bytes);
+  if (rc == PVW_OK) {
+    if (hipMemcpyAsync(w->scratch, polys, bytes, hipMemcpyHostToDevice, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+    if (rc == PVW_OK) {
+      ProfScope ps(c, "ntt", w->stream);
+      if (launch_ntt((u64*)w->scratch, count, false, c->dt, c->L, c->l, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "ntt launch failed");
+    }
+    if (rc == PVW_OK && (hipMemcpyAsync(polys, w->scratch, bytes, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                         hipStreamSynchronize(w->stream) != hipSuccess)) rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  }
+  ws_release(c, w);
+  return rc;
+}
+int32_t pvw_ntt_inverse(pvw_ctx* c, uint64_t* polys, size_t count) {
+  if (!c || (!polys && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (count == 0) return PVW_OK;
+  PVW_TRY(ensure_device(c));
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  const size_t bytes = count * c->poly() * 8;
+  int32_t rc = ws_scratch(w, bytes);
+  if (rc == PVW_OK) {
+    if (hipMemcpyAsync(w->scratch, polys, bytes, hipMemcpyHostToDevice, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+    if (rc == PVW_OK) {
+      ProfScope ps(c, "intt", w->stream);
+      if (launch_ntt((u64*)w->scratch, count, true, c->dt, c->L, c->l, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "intt launch failed");
+    }
+    if (rc == PVW_OK && (hipMemcpyAsync(polys, w->scratch, bytes, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                         hipStreamSynchronize(w->stream) != hipSuccess)) rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  }
+  ws_release(c, w);
+  return rc;
+}
+
+static int32_t small_to_poly_impl(pvw_ctx* c, const int64_t* coeffs, const uint64_t* scalar, size_t count,
+                                  uint64_t* polys, uint32_t repr) {
+  PVW_TRY(check_repr(repr));
+  if (count == 0) return PVW_OK;
+  PVW_TRY(ensure_device(c));
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  const size_t inb = count * c->l * 8, outb = count * c->poly() * 8, scb = scalar ? count * 8 : 0;
+  const size_t off_out = (inb + 255) & ~(size_t)255, off_sc = off_out + ((outb + 255) & ~(size_t)255);
+  int32_t rc = ws_scratch(w, off_sc + scb + 256);
+  if (rc == PVW_OK) {
+    char* base = (char*)w->scratch;
+    if (hipMemcpyAsync(base, coeffs, inb, hipMemcpyHostToDevice, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+    if (rc == PVW_OK && scalar && hipMemcpyAsync(base + off_sc, scalar, scb, hipMemcpyHostToDevice, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+    if (rc == PVW_OK) {
+      ProfScope ps(c, "prep", w->stream);
+      if (launch_prep((const i64*)base, scalar ? (const u64*)(base + off_sc) : nullptr, (u64*)(base + off_out),
+                      c->poly(), c->l, (u32)count, repr == PVW_REPR_NTT, c->dt, c->L, c->l, w->stream) != hipSuccess)
+        rc = fail(PVW_ERR_INTERNAL, "prep launch failed");
+    }
+    if (rc == PVW_OK && (hipMemcpyAsync(polys, base + off_out, outb, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                         hipStreamSynchronize(w->stream) != hipSuccess)) rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  }
+  ws_release(c, w);
+  return rc;
+}
+int32_t pvw_small_to_poly(pvw_ctx* c, const int64_t* coeffs, size_t count, uint64_t* polys, uint32_t repr) {
+  if (!c || ((!coeffs || !polys) && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  return small_to_poly_impl(c, coeffs, nullptr, count, polys, repr);
+}
+int32_t pvw_encode_scalar(const pvw_ctx* cc, int64_t scalar, uint64_t* poly_out, uint32_t repr) {
+  pvw_ctx* c = const_cast<pvw_ctx*>(cc);
+  if (!c || !poly_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  std::vector<int64_t> zero(c->l, 0);
+  uint64_t s = (uint64_t)scalar;
+  return small_to_poly_impl(c, zero.data(), &s, 1, poly_out, repr);
+}
+
+// ------------------------------------------------------------------------ encrypt
+static int32_t encrypt_checks(pvw_ctx* c, size_t num_scalars, const pvw_randomness_t* rnd, uint32_t out_repr) {
+  PVW_TRY(check_repr(out_repr));
+  if (!rnd) return fail(PVW_ERR_INVALID_PARAMETERS, "randomness is NULL");
+  if (num_scalars != c->n) {                                                        // encryption.rs:109-115
+    char buf[96];
+    snprintf(buf, sizeof buf, "Must provide exactly n=%u scalars, got %zu", c->n, num_scalars);
+    return fail(PVW_ERR_INVALID_PARAMETERS, buf);
+  }
+  if (c->num_keys < c->party_hi)                                                    // :117-121
+    return fail(PVW_ERR_INVALID_PARAMETERS, "Global public key is not complete (missing party keys)");
+  if (!c->crs_loaded) return fail(PVW_ERR_CRS, "CRS not loaded");
+  int32_t ok = 0;
+  pvw_ctx_verify_correctness_condition(c, &ok);
+  if (!ok)                                                                          // :124-128
+    return fail(PVW_ERR_INVALID_PARAMETERS, "Parameters do not satisfy correctness condition - decryption may fail");
+  if (rnd->mode == PVW_RND_EXPLICIT) {
+    if (!rnd->r || (!rnd->e1 && c->rowsA()) || (!rnd->e2 && c->rowsB()))
+      return fail(PVW_ERR_INVALID_PARAMETERS, "explicit randomness pointers are NULL");
+  } else if (rnd->mode != PVW_RND_SEED) {
+    return fail(PVW_ERR_INVALID_PARAMETERS, "unknown randomness mode");
+  }
+  return PVW_OK;
+}
+
+// all pointers are device pointers; explicit r/e1/e2 are GLOBAL arrays ([k][l], [k][l], [n][l])
+static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, const pvw_randomness_t* rnd,
+                               u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
+  const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
+  const size_t P = c->poly();
+  const i64 *d_r, *d_e1, *d_e2;
+  if (rnd->mode == PVW_RND_SEED) {
+    SampleJob jr{}, j1{}, j2{};
+    PVW_TRY(cbd_job(c->variance, jr));                                              // encryption.rs:135-142
+    jr.domain = DOM_R; jr.index0 = 0; jr.count = k; jr.out_poly0 = 0;
+    j1.kind = SAMPLE_UNIFORM; j1.domain = DOM_E1; j1.index0 = c->c1_lo; j1.count = rA; j1.out_poly0 = k; j1.bound = c->b1;       // :161-167
+    j2.kind = SAMPLE_UNIFORM; j2.domain = DOM_E2; j2.index0 = c->party_lo; j2.count = rB; j2.out_poly0 = 2 * k; j2.bound = c->b2; // :196
+    ProfScope ps(c, "sample", s);
+    PVW_HIP(launch_sample(w->small, make_key(rnd->seed), l, jr, j1, j2, s));
+    d_r = w->small;
+    d_e1 = w->small + (size_t)k * l;
+    d_e2 = w->small + (size_t)2 * k * l;
+  } else {
+    d_r = rnd->r;
+    d_e1 = rnd->e1 + (size_t)c->c1_lo * l;
+    d_e2 = rnd->e2 + (size_t)c->party_lo * l;
+  }
+  {
+    ProfScope ps(c, "prep", s);
+    // r -> r-hat [L][k][l]   (encryption.rs:147-154)
+    PVW_HIP(launch_prep(d_r, nullptr, w->rhat, l, (size_t)k * l, k, true, c->dt, L, l, s));
+    // NTT(e1) -> c1 rows; NTT(e2) + scalar*g-hat -> c2 rows (the MAC kernel adds onto them)
+    PVW_HIP(launch_prep(d_e1, nullptr, d_c1, P, l, rA, true, c->dt, L, l, s));
+    PVW_HIP(launch_prep(d_e2, d_scalars + c->party_lo, d_c2, P, l, rB, true, c->dt, L, l, s));
+  }
+  {
+    ProfScope ps(c, "mac_rows", s);
+    MacSection a{c->dA, d_c1, d_c1, rA, 0}, b{c->dB, d_c2, d_c2, rB, 0};
+    PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s));                      // crs.rs:188-201, encryption.rs:177-200
+  }
+  if (out_repr == PVW_REPR_POWER) {
+    ProfScope ps(c, "intt", s);
+    PVW_HIP(launch_ntt(d_c1, rA, true, c->dt, L, l, s));
+    PVW_HIP(launch_ntt(d_c2, rB, true, c->dt, L, l, s));
+  }
+  return PVW_OK;
+}
+
+int32_t pvw_encrypt_device(pvw_ctx* c, const uint64_t* d_scalars, size_t num_scalars, const pvw_randomness_t* rnd,
+                           uint64_t* d_c1, uint64_t* d_c2, uint32_t out_repr, void* stream) {
+  if (!c || !d_scalars || (!d_c1 && c->rowsA()) || (!d_c2 && c->rowsB())) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(encrypt_checks(c, num_scalars, rnd, out_repr));
+  PVW_TRY(ensure_device(c));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  Workspace* w;
+  PVW_TRY(ws_for_stream(c, s, &w));
+  return encrypt_enqueue(c, w, d_scalars, rnd, d_c1, d_c2, out_repr, s);
+}
+
+int32_t pvw_encrypt(pvw_ctx* c, const uint64_t* scalars, size_t num_scalars, const pvw_randomness_t* rnd,
+                    uint64_t* c1_out, uint64_t* c2_out, uint32_t out_repr) {
+  if (!c || !scalars || !c1_out || !c2_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(encrypt_checks(c, num_scalars, rnd, out_repr));
+  PVW_TRY(ensure_device(c));
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  int32_t rc = ws_host_buffers(c, w);
+  const size_t l = c->l, k = c->k, P = c->poly();
+  pvw_randomness_t dr = *rnd;
+  if (rc == PVW_OK && rnd->mode == PVW_RND_EXPLICIT) {
+    // upload the explicit small polynomials as global arrays
+    const size_t words = (2 * k + c->n) * l;
+    rc = ws_scratch(w, words * 8);
+    if (rc == PVW_OK) {
+      i64* base = (i64*)w->scratch;
+      if (hipMemcpyAsync(base, rnd->r, k * l * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess ||
+          hipMemcpyAsync(base + k * l, rnd->e1, k * l * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess ||
+          hipMemcpyAsync(base + 2 * k * l, rnd->e2, (size_t)c->n * l * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess)
+        rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+      dr.r = base;
+      dr.e1 = base + k * l;
+      dr.e2 = base + 2 * k * l;
+    }
+  }
+  if (rc == PVW_OK && hipMemcpyAsync(w->scalars, scalars, (size_t)c->n * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess)
+    rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+  if (rc == PVW_OK) rc = encrypt_enqueue(c, w, w->scalars, &dr, w->c1, w->c2, out_repr, w->stream);
+  if (rc == PVW_OK &&
+      (hipMemcpyAsync(c1_out + (size_t)c->c1_lo * P, w->c1, (size_t)c->rowsA() * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+       hipMemcpyAsync(c2_out + (size_t)c->party_lo * P, w->c2, (size_t)c->rowsB() * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+       hipStreamSynchronize(w->stream) != hipSuccess))
+    rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  ws_release(c, w);
+  return rc;
+}
+
+// ------------------------------------------------------------------------ decode (host, integers)
+static BigInt center(const BigInt& v, const pvw_ctx* c) {              // decryption.rs:140-152
+  return v > c->halfQ ? v - c->Q : v;
+}
+static BigInt crt_lift(const pvw_ctx* c, const uint64_t* poly, u32 coeff) {
+  BigInt acc;
+  for (u32 i = 0; i < c->L; ++i) {
+    u64 t = mulmod(poly[(size_t)i * c->l + coeff], c->crt_inv[i], c->mods[i]);
+    acc = acc + c->crt_qi[i] * BigInt(t);
+  }
+  return acc % c->Q;
+}
+static uint64_t decode_one(const pvw_ctx* c, const uint64_t* noisy) {   // decryption.rs:10-58
+  const u32 l = c->l;
+  const BigInt &Q = c->Q, &D = c->delta;
+  std::vector<BigInt> z(l), tmp(l), noise(l);
+  for (u32 j = 0; j < l; ++j) z[j] = center(crt_lift(c, noisy, j), c);                  // :109-137
+  for (u32 i = 0; i + 1 < l; ++i) tmp[i] = (z[i] * D - z[i + 1]).mod_floor(Q);          // :19-27
+  BigInt last = tmp[0];
+  for (u32 i = 1; i + 1 < l; ++i) last = (last * D + tmp[i]).mod_floor(Q);             // :30-33
+  {                                                                                     // reduce_modulo_poly :154-178
+    BigInt poly_const = center(last, c);
+    BigInt mod_const = center(c->delta_pow.mod_floor(Q), c);
+    BigInt reduced = poly_const % mod_const;
+    BigInt half = mod_const / BigInt(2);
+    if (reduced > half) reduced = reduced - mod_const;
+    else if (reduced < -half) reduced = reduced + mod_const;
+    tmp[l - 1] = reduced.mod_floor(Q);
+  }
+  noise[l - 1] = tmp[l - 1];
+  const BigInt delta_const = center(D.mod_floor(Q), c);
+  const BigInt two_delta = delta_const * BigInt(2);
+  for (u32 i = l - 1; i-- > 0;) {                                                       // :44-48, divide_by_delta_rns :180-207
+    BigInt p = center((noise[i + 1] - tmp[i]).mod_floor(Q), c);
+    BigInt quo;
+    if (!delta_const.is_zero()) {
+      BigInt twice = p * BigInt(2);
+      quo = p.is_negative() ? (twice - delta_const) / two_delta : (twice + delta_const) / two_delta;
+    }
+    noise[i] = quo.mod_floor(Q);
+  }
+  BigInt plain = center((-z[0] - noise[0]).mod_floor(Q), c);                            // :51-53
+  if (plain.is_negative()) {                                                            // :226-247
+    BigInt abs = -plain;
+    if (abs <= BigInt(1000)) return 0;
+    BigInt pos = (plain + Q) % Q;
+    return pos.fits_u64() ? pos.low_u64() : 0;
+  }
+  return plain.fits_u64() ? plain.low_u64() : 0;
+}
+
+int32_t pvw_decode(const pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* out) {
+  if (!c || ((!noisy || !out) && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  const size_t P = c->poly();
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 32) nt = 32;
+  if (count < 64) nt = 1;
+  if (nt == 1) {
+    for (size_t d = 0; d < count; ++d) out[d] = decode_one(c, noisy + d * P);
+    return PVW_OK;
+  }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([=]() {
+      for (size_t d = t; d < count; d += nt) out[d] = decode_one(c, noisy + d * P);
+    });
+  for (auto& x : th) x.join();
+  return PVW_OK;
+}
+
+// ------------------------------------------------------------------------ decrypt
+static int32_t decrypt_enqueue(pvw_ctx* c, Workspace* w, const i64* d_sk, u64* d_c1s, u64* d_c2col, size_t D,
+                               uint32_t in_repr, u64* d_noisy, hipStream_t s, bool inputs_mutable) {
+  const u32 k = c->k, l = c->l, L = c->L;
+  const size_t P = c->poly();
+  {
+    ProfScope ps(c, "prep", s);
+    // NTT(sk[j]) in the ciphertext layout [k][L][l]   (secret_key.rs:98-112, once per call)
+    PVW_HIP(launch_prep(d_sk, nullptr, w->rhat, P, l, k, true, c->dt, L, l, s));
+  }
+  if (in_repr == PVW_REPR_POWER) {
+    if (!inputs_mutable) return fail(PVW_ERR_INVALID_FORMAT, "power-basis ciphertexts need a mutable device buffer");
+    ProfScope ps(c, "ntt", s);
+    PVW_HIP(launch_ntt(d_c1s, D * k, false, c->dt, L, l, s));
+    PVW_HIP(launch_ntt(d_c2col, D, false, c->dt, L, l, s));
+  }
+  {
+    ProfScope ps(c, "decrypt_mac", s);
+    PVW_HIP(launch_decrypt_mac(d_c1s, w->rhat, d_c2col, d_noisy, c->dt, k, L, l, D, s));   // decryption.rs:257-274
+  }
+  {
+    ProfScope ps(c, "intt", s);
+    PVW_HIP(launch_ntt(d_noisy, D, true, c->dt, L, l, s));                                  // :116
+  }
+  return PVW_OK;
+}
+
+int32_t pvw_decrypt_noisy_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t* d_c1s, const uint64_t* d_c2col,
+                                 size_t D, uint32_t in_repr, uint64_t* d_noisy, void* stream) {
+  if (!c || !d_sk || ((!d_c1s || !d_c2col || !d_noisy) && D)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(in_repr));
+  if (in_repr != PVW_REPR_NTT) return fail(PVW_ERR_INVALID_FORMAT, "device decrypt takes NTT-domain ciphertexts");
+  PVW_TRY(ensure_device(c));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  Workspace* w;
+  PVW_TRY(ws_for_stream(c, s, &w));
+  return decrypt_enqueue(c, w, d_sk, const_cast<u64*>(d_c1s), const_cast<u64*>(d_c2col), D, in_repr, d_noisy, s, false);
+}
+
+int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, const uint64_t* c2col, size_t D,
+                          uint32_t in_repr, uint64_t* out_u64, uint64_t* noisy_out) {
+  if (!c || !sk) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (D == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "No ciphertexts provided");          // decryption.rs:286-290
+  if (!c1s || !c2col || !out_u64) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(in_repr));
+  PVW_TRY(ensure_device(c));
+  const size_t k = c->k, l = c->l, P = c->poly();
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  // dealers per pass: bounded staging (<= ~1 GiB of ciphertext)
+  size_t per = ((size_t)1 << 30) / (k * P * 8);
+  if (per == 0) per = 1;
+  if (per > D) per = D;
+  const size_t b_sk = (k * l * 8 + 255) & ~(size_t)255;
+  const size_t b_c1 = (per * k * P * 8 + 255) & ~(size_t)255;
+  const size_t b_c2 = (per * P * 8 + 255) & ~(size_t)255;
+  int32_t rc = ws_scratch(w, b_sk + b_c1 + 2 * b_c2);
+  std::vector<uint64_t> noisy_host;
+  uint64_t* nz = noisy_out;
+  if (!nz) { noisy_host.resize(D * P); nz = noisy_host.data(); }
+  if (rc == PVW_OK) {
+    char* base = (char*)w->scratch;
+    i64* d_sk = (i64*)base;
+    u64* d_c1 = (u64*)(base + b_sk);
+    u64* d_c2 = (u64*)(base + b_sk + b_c1);
+    u64* d_nz = (u64*)(base + b_sk + b_c1 + b_c2);
+    if (hipMemcpyAsync(d_sk, sk, k * l * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+    for (size_t d0 = 0; rc == PVW_OK && d0 < D; d0 += per) {
+      const size_t cnt = (D - d0) < per ? (D - d0) : per;
+      if (hipMemcpyAsync(d_c1, c1s + d0 * k * P, cnt * k * P * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess ||
+          hipMemcpyAsync(d_c2, c2col + d0 * P, cnt * P * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess) {
+        rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+        break;
+      }
+      rc = decrypt_enqueue(c, w, d_sk, d_c1, d_c2, cnt, in_repr, d_nz, w->stream, true);
+      if (rc == PVW_OK && (hipMemcpyAsync(nz + d0 * P, d_nz, cnt * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                           hipStreamSynchronize(w->stream) != hipSuccess))
+        rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+    }
+  }
+  ws_release(c, w);
+  if (rc != PVW_OK) return rc;
+  return pvw_decode(c, nz, D, out_u64);
+}
+
+// ------------------------------------------------------------------------ key generation
+// b_i = s_i * A + e_i: for every party the k-term inner products over A's COLUMNS, i.e. one
+// mac_rows pass over the transposed CRS per party (public_key.rs:111-147, crs.rs:138-171).
+// Round-1 implementation: the CRS is transposed once into a temporary tiled matrix and each
+// party's public key is one mac_rows launch with s-hat_i in the role of r-hat.
+int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, const int64_t* ek, const uint8_t seed[32]) {
+  if (!c || !sk) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (!ek && !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "either explicit key errors or a seed is required");
+  PVW_TRY(check_party_range(c, lo, hi));
+  PVW_TRY(ensure_device(c));
+  if (!c->crs_loaded) return fail(PVW_ERR_CRS, "CRS not loaded");
+  if (c->rowsA() != c->k) return fail(PVW_ERR_KEY_GENERATION, "key generation needs the full CRS on this context");
+  PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
+  const u32 a = lo > c->party_lo ? lo : c->party_lo, b = hi < c->party_hi ? hi : c->party_hi;
+  const u32 k = c->k, l = c->l, L = c->L;
+  const size_t P = c->poly();
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  hipStream_t s = w->stream;
+  // scratch: A in API layout [k][k][P] | A^T tiled | per-party: sk,ek small [2k][l], b row [k][P]
+  const size_t b_api = ((size_t)k * k * P * 8 + 255) & ~(size_t)255;
+  const size_t b_tt = (c->tiled_words(k) * 8 + 255) & ~(size_t)255;
+  const size_t b_small = ((size_t)2 * k * l * 8 + 255) & ~(size_t)255;
+  const size_t b_row = ((size_t)k * P * 8 + 255) & ~(size_t)255;
+  int32_t rc = ws_scratch(w, 2 * b_api + b_tt + b_small + b_row);
+  if (rc == PVW_OK) {
+    char* base = (char*)w->scratch;
+    u64* d_api = (u64*)base;
+    u64* d_apiT = (u64*)(base + b_api);
+    u64* d_tt = (u64*)(base + 2 * b_api);
+    i64* d_small = (i64*)(base + 2 * b_api + b_tt);
+    u64* d_row = (u64*)(base + 2 * b_api + b_tt + b_small);
+    // A -> API layout -> transpose polynomials (A^T[c][j] = A[j][c]) -> tiled
+    bool okk = launch_untile(c->dA, d_api, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
+    for (u32 j = 0; okk && j < k; ++j)
+      okk = hipMemcpy2DAsync(d_apiT + (size_t)j * P, (size_t)k * P * 8, d_api + (size_t)j * k * P, P * 8, P * 8, k,
+                             hipMemcpyDeviceToDevice, s) == hipSuccess;
+    okk = okk && hipMemsetAsync(d_tt, 0, c->tiled_words(k) * 8, s) == hipSuccess;
+    okk = okk && launch_tile(d_apiT, d_tt, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
+    if (!okk) rc = fail(PVW_ERR_INTERNAL, "CRS transpose failed");
+    for (u32 p = a; rc == PVW_OK && p < b; ++p) {
+      const int64_t* skp = sk + (size_t)(p - lo) * k * l;
+      if (hipMemcpyAsync(d_small, skp, (size_t)k * l * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = fail(PVW_ERR_INTERNAL, "H2D failed"); break; }
+      if (ek) {
+        if (hipMemcpyAsync(d_small + (size_t)k * l, ek + (size_t)(p - lo) * k * l, (size_t)k * l * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = fail(PVW_ERR_INTERNAL, "H2D failed"); break; }
+      } else {
+        SampleJob j{}, z{};
+        j.kind = SAMPLE_UNIFORM; j.domain = DOM_EKEY; j.index0 = p * k; j.count = k; j.out_poly0 = k; j.bound = c->b1;   // public_key.rs:128-132
+        if (launch_sample(d_small, make_key(seed), l, j, z, z, s) != hipSuccess) { rc = fail(PVW_ERR_INTERNAL, "sample launch failed"); break; }
+      }
+      ProfScope ps(c, "keygen", s);
+      bool ok2 = launch_prep(d_small, nullptr, w->rhat, l, (size_t)k * l, k, true, c->dt, L, l, s) == hipSuccess;        // secret_key.rs:98-112
+      ok2 = ok2 && launch_prep(d_small + (size_t)k * l, nullptr, d_row, P, l, k, true, c->dt, L, l, s) == hipSuccess;     // NTT(e_i)
+      MacSection sa{d_tt, d_row, d_row, k, 0}, sb{nullptr, nullptr, nullptr, 0, 0};
+      ok2 = ok2 && launch_mac_rows(sa, sb, w->rhat, c->dt, k, L, l, s) == hipSuccess;                                       // crs.rs:152-168
+      // d_row is [k polys][P] = one row of B in API layout -> tile into B
+      ok2 = ok2 && launch_tile(d_row, c->dB, 1, p - c->party_lo, k, L, l, false, c->dt, s) == hipSuccess;
+      if (!ok2) rc = fail(PVW_ERR_KEY_GENERATION, "keygen launch failed");
+    }
+    if (rc == PVW_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");
+  }
+  ws_release(c, w);
+  if (rc == PVW_OK && hi > c->num_keys) c->num_keys = hi;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// pvw_kernels.h -- launch interface of the gfx950 kernels (pvw_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pvw_arith.h"
+#include "pvw_chacha.h"
+
+namespace pvw {
+
+enum { DOM_R = 0, DOM_E1 = 1, DOM_E2 = 2, DOM_SK = 3, DOM_EKEY = 4, DOM_CRS = 5, DOM_GAUSS = 6, DOM_PK = 7 };
+
+// per-context device tables (all device pointers)
+struct DevTables {
+  const Mod* mods;   // [L]
+  const u64* tw;     // [L][l]  psi^bitrev(i)
+  const u64* itw;    // [L][l]  psi^-bitrev(i)
+  const u64* linv;   // [L]     l^-1 mod q
+  const u64* ghat;   // [L][l]  NTT(gadget)              (parameters.rs:288-308)
+  const u64* gpow;   // [L][l]  gadget residues D^j mod q (power basis)
+};
+
+enum { SAMPLE_CBD = 0, SAMPLE_UNIFORM = 1 };
+struct SampleJob {
+  u32 kind;       // SAMPLE_CBD | SAMPLE_UNIFORM
+  u32 domain;     // ChaCha stream domain
+  u32 index0;     // first polynomial index (stream id low word)
+  u32 count;      // polynomials
+  u32 out_poly0;  // first output polynomial slot
+  u32 cbd_half;   // variance == 0.5 special case
+  u32 cbd_v;      // (usize)variance otherwise
+  u64 bound;      // uniform bound
+};
+
+// one section of the streamed tiled matrix: out[row] = sum_j M[row][j]*rhat[j] + addend[row]
+// (addend may alias out; NULL = none).  row_blocks is filled in by the launcher.
+struct MacSection {
+  const u64* M;
+  const u64* addend;
+  u64* out;
+  u32 nrows;
+  u32 row_blocks;
+};
+// c1 (section a: A-hat rows) and c2 (section b: B-hat rows) in a single launch
+hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat,
+                           const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s);
+hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t stride_poly,
+                       size_t stride_limb, u32 count, bool do_ntt, const DevTables& t, u32 L,
+                       u32 ell, hipStream_t s);
+hipError_t launch_ntt(u64* polys, size_t count, bool inverse, const DevTables& t, u32 L, u32 ell,
+                      hipStream_t s);
+hipError_t launch_tile(const u64* src, u64* M, u32 rows, u32 row0_tiled, u32 k, u32 L, u32 ell,
+                       bool ntt_first, const DevTables& t, hipStream_t s);
+hipError_t launch_untile(const u64* M, u64* dst, u32 rows, u32 row0_tiled, u32 k, u32 L, u32 ell,
+                         bool intt_after, const DevTables& t, hipStream_t s);
+hipError_t launch_fill_uniform_tiled(u64* M, const ChaChaKey& key, u32 domain, u32 rows,
+                                     u32 row0_tiled, u32 grow0, u32 k, u32 L, u32 ell,
+                                     const DevTables& t, hipStream_t s);
+hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJob& j0,
+                         const SampleJob& j1, const SampleJob& j2, hipStream_t s);
+hipError_t launch_gaussian(i64* out, const ChaChaKey& key, u32 index0, u32 count, u64 bound,
+                           hipStream_t s);
+hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col, u64* noisy,
+                              const DevTables& t, u32 k, u32 L, u32 ell, size_t dealers,
+                              hipStream_t s);
+
+}  // namespace pvw

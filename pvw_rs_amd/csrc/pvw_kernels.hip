@@ -1,0 +1,524 @@
+// pvw_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels of the PVW hot path.
+//
+// Data layout in HBM
+//   "tiled matrix" M (A-hat rows followed by B-hat rows) -- the streamed operand of
+//   encrypt (c1 = A r + e1, c2 = B r + e2 + m g; src/crypto/encryption.rs:158,177-200,
+//   src/params/crs.rs:188-201):
+//        M[row_block][limb][j][rho][slot]        rho < R = 128/l, slot < l
+//   One (row_block, limb, j) tile is 128 u64 = 1 KiB = exactly one 16-byte-per-lane
+//   wave64 load; a (row_block, limb) pair is k contiguous tiles.  A lane owns the same
+//   (row, slot pair) for every j, so the k-term inner product needs no cross-lane step.
+//   r-hat is stored [limb][j][slot] so the slice a wave needs is contiguous.
+//   Everything that crosses the C ABI uses the reference's layout, [..][limb][slot]
+//   (src/params/parameters.rs:433-458).
+//
+// Roofline: every kernel here is HBM-bound integer work (no dense contraction, no MFMA):
+//   mac_rows      8 B read per modular MAC (1 MAC = 4 v_mad_u64_u32 + 4 v_addc)
+//   decrypt_mac   same, on the ciphertext layout as it arrives
+//   the rest      O(n + k) polynomials, launch-latency sized
+#include <hip/hip_runtime.h>
+
+#include "pvw_arith.h"
+#include "pvw_chacha.h"
+#include "pvw_kernels.h"
+
+namespace pvw {
+
+typedef u64 v2u64 __attribute__((ext_vector_type(2)));  // one 16-byte lane access
+
+// ------------------------------------------------------------------------------------
+// mac_rows: out[row][limb][slot] = sum_j M[row][j][limb][slot] * rhat[j][limb][slot] + addend
+// grid = row_blocks * L workgroups of 256 threads; the 4 waves split the j range, each
+// streaming a contiguous run of 1-KiB tiles; r-hat slices are staged in wave-private LDS.
+// ------------------------------------------------------------------------------------
+template <int ELL>
+__global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection sb,
+                                                        const u64* __restrict__ rhat,
+                                                        const Mod* __restrict__ mods, u32 k, u32 L) {
+  constexpr int HALF = ELL / 2;   // 16-byte slot pairs per polynomial limb
+  constexpr int R = 128 / ELL;    // rows per tile
+  constexpr int JC = ELL <= 16 ? 64 : (ELL == 32 ? 32 : 16);  // j per staged r-hat chunk (LDS <= 32 KiB)
+  constexpr int U = 8;            // tiles in flight per wave per buffer
+  __shared__ v2u64 lds[4 * JC * HALF];
+
+  // section a = A-hat rows (c1), section b = B-hat rows (c2): one launch covers both
+  const u32 limb = blockIdx.x % L;
+  const u32 rbg = blockIdx.x / L;
+  const bool in_a = rbg < sa.row_blocks;
+  const u32 rb = in_a ? rbg : rbg - sa.row_blocks;
+  const u64* __restrict__ M = in_a ? sa.M : sb.M;
+  const u64* addend = in_a ? sa.addend : sb.addend;
+  u64* out = in_a ? sa.out : sb.out;
+  const u32 nrows = in_a ? sa.nrows : sb.nrows;
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 sp = lane % HALF, rho = lane / HALF;
+  const u32 kq = (k + 3) / 4;
+  const u32 j0 = wave * kq < k ? wave * kq : k;
+  const u32 j1 = (j0 + kq) < k ? (j0 + kq) : k;
+
+  const v2u64* Mp =
+      reinterpret_cast<const v2u64*>(M + ((size_t)rb * L + limb) * (size_t)k * 128) + lane;
+  const v2u64* rp = reinterpret_cast<const v2u64*>(rhat + (size_t)limb * k * ELL);
+  v2u64* lw = lds + wave * (JC * HALF);
+
+  Acc a0, a1;
+  acc_zero(a0);
+  acc_zero(a1);
+
+  for (u32 jc = j0; jc < j1; jc += JC) {
+    const u32 cnt = (j1 - jc) < (u32)JC ? (j1 - jc) : (u32)JC;
+    __builtin_amdgcn_wave_barrier();
+    for (u32 idx = lane; idx < cnt * HALF; idx += 64) lw[idx] = rp[(size_t)jc * HALF + idx];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const v2u64* mp = Mp + (size_t)jc * 64;
+    u32 jj = 0;
+    if (cnt >= U) {
+      v2u64 x[U], xn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(mp + (size_t)u * 64);
+      for (; jj + 2 * U <= cnt; jj += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          xn[u] = __builtin_nontemporal_load(mp + (size_t)(jj + U + u) * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v2u64 y = lw[(jj + u) * HALF + sp];
+          acc_mac_dev(a0, x[u].x, y.x);
+          acc_mac_dev(a1, x[u].y, y.y);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = xn[u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        v2u64 y = lw[(jj + u) * HALF + sp];
+        acc_mac_dev(a0, x[u].x, y.x);
+        acc_mac_dev(a1, x[u].y, y.y);
+      }
+      jj += U;
+    }
+    for (; jj < cnt; ++jj) {
+      v2u64 xv = mp[(size_t)jj * 64];
+      v2u64 y = lw[jj * HALF + sp];
+      acc_mac_dev(a0, xv.x, y.x);
+      acc_mac_dev(a1, xv.y, y.y);
+    }
+  }
+
+  // one Barrett reduction per wave partial ("wavefront-wide": q, ratio are SGPRs)
+  const Mod m = mods[limb];
+  v2u64 part;
+  part.x = acc_reduce(a0, m);
+  part.y = acc_reduce(a1, m);
+  __syncthreads();  // all waves are done with their r-hat slices
+  lds[wave * 64 + lane] = part;
+  __syncthreads();
+  if (wave == 0) {
+    const u32 row = rb * R + rho;
+    if (row < nrows) {
+      v2u64 s = lds[lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        v2u64 t = lds[w * 64 + lane];
+        s.x = addmod(s.x, t.x, m.q);
+        s.y = addmod(s.y, t.y, m.q);
+      }
+      const size_t o = (((size_t)row * L + limb) * ELL) / 2 + sp;
+      if (addend) {
+        v2u64 e = reinterpret_cast<const v2u64*>(addend)[o];
+        s.x = addmod(s.x, e.x, m.q);
+        s.y = addmod(s.y, e.y, m.q);
+      }
+      reinterpret_cast<v2u64*>(out)[o] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// prep: small signed coefficients -> RNS -> l-point NTT (+ scalar * g-hat), one thread per
+// (polynomial, limb).  Serves r-hat, the e1/e2 addends, encode_scalar
+// (src/params/parameters.rs:346-367) and Poly::from_coefficients + NTT
+// (encryption.rs:147-154, secret_key.rs:98-112).
+// ------------------------------------------------------------------------------------
+template <int ELL>
+__global__ __launch_bounds__(64) void prep_kernel(const i64* __restrict__ coeffs,
+                                                   const u64* __restrict__ scalars,
+                                                   u64* __restrict__ out, size_t stride_poly,
+                                                   size_t stride_limb, u32 count, u32 L,
+                                                   u32 do_ntt, DevTables t) {
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= count * L) return;
+  const u32 p = tid / L, limb = tid % L;
+  const Mod m = t.mods[limb];
+  u64 a[ELL];
+#pragma unroll
+  for (int s = 0; s < ELL; ++s) a[s] = signed_residue(coeffs[(size_t)p * ELL + s], m);
+  if (do_ntt) ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, m);
+  if (scalars) {
+    // `scalars[i] as i64` wrap (encryption.rs:195), then scalar * g  (parameters.rs:346-367)
+    const u64 mr = signed_residue((i64)scalars[p], m);
+    const u64* g = (do_ntt ? t.ghat : t.gpow) + (size_t)limb * ELL;
+#pragma unroll
+    for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod(mr, g[s], m), m.q);
+  }
+  u64* o = out + (size_t)p * stride_poly + (size_t)limb * stride_limb;
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2)
+    *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
+}
+
+// in-place change_representation on [count][L][l] polynomials
+template <int ELL>
+__global__ __launch_bounds__(64) void ntt_kernel(u64* __restrict__ polys, u32 count, u32 L,
+                                                  u32 inverse, DevTables t) {
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= count * L) return;
+  const u32 limb = tid % L;
+  const Mod m = t.mods[limb];
+  u64* p = polys + (size_t)tid * ELL;
+  u64 a[ELL];
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2) {
+    v2u64 v = *reinterpret_cast<const v2u64*>(p + s);
+    a[s] = v.x;
+    a[s + 1] = v.y;
+  }
+  if (inverse) ntt_inverse<ELL>(a, t.itw + (size_t)limb * ELL, t.linv[limb], m);
+  else ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, m);
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2)
+    *reinterpret_cast<v2u64*>(p + s) = (v2u64){a[s], a[s + 1]};
+}
+
+// ------------------------------------------------------------------------------------
+// tile / untile: API layout [row][j][L][l] <-> tiled M, optional NTT on the way.
+// One thread per (row, j, limb).
+// ------------------------------------------------------------------------------------
+template <int ELL>
+__global__ __launch_bounds__(256) void tile_kernel(const u64* __restrict__ src, u64* __restrict__ M,
+                                                    u32 rows, u32 row0_tiled, u32 k, u32 L,
+                                                    u32 ntt_first, DevTables t) {
+  constexpr int R = 128 / ELL;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (size_t)rows * k * L) return;
+  const u32 limb = tid % L;
+  const u32 j = (tid / L) % k;
+  const u32 row = tid / ((size_t)L * k);
+  const u64* p = src + tid * ELL;
+  u64 a[ELL];
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2) {
+    v2u64 v = *reinterpret_cast<const v2u64*>(p + s);
+    a[s] = v.x;
+    a[s + 1] = v.y;
+  }
+  if (ntt_first) ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.mods[limb]);
+  const u32 trow = row0_tiled + row;
+  u64* o = M + (((size_t)(trow / R) * L + limb) * k + j) * 128 + (trow % R) * ELL;
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2)
+    *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
+}
+
+template <int ELL>
+__global__ __launch_bounds__(256) void untile_kernel(const u64* __restrict__ M, u64* __restrict__ dst,
+                                                      u32 rows, u32 row0_tiled, u32 k, u32 L,
+                                                      u32 intt_after, DevTables t) {
+  constexpr int R = 128 / ELL;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (size_t)rows * k * L) return;
+  const u32 limb = tid % L;
+  const u32 j = (tid / L) % k;
+  const u32 row = tid / ((size_t)L * k);
+  const u32 trow = row0_tiled + row;
+  const u64* p = M + (((size_t)(trow / R) * L + limb) * k + j) * 128 + (trow % R) * ELL;
+  u64 a[ELL];
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2) {
+    v2u64 v = *reinterpret_cast<const v2u64*>(p + s);
+    a[s] = v.x;
+    a[s + 1] = v.y;
+  }
+  if (intt_after) ntt_inverse<ELL>(a, t.itw + (size_t)limb * ELL, t.linv[limb], t.mods[limb]);
+  u64* o = dst + tid * ELL;
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2)
+    *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
+}
+
+// uniform residues straight into the tiled matrix: polynomial (grow, j), limb i uses ChaCha8
+// stream (domain << 32) | ((grow*k + j)*L + i)   (grow = global row index)
+template <int ELL>
+__global__ __launch_bounds__(256) void fill_uniform_tiled_kernel(u64* __restrict__ M, ChaChaKey key,
+                                                                  u32 domain, u32 rows,
+                                                                  u32 row0_tiled, u32 grow0, u32 k,
+                                                                  u32 L, DevTables t) {
+  constexpr int R = 128 / ELL;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (size_t)rows * k * L) return;
+  const u32 limb = tid % L;
+  const u32 j = (tid / L) % k;
+  const u32 row = tid / ((size_t)L * k);
+  ChaChaRng g;
+  g.init(key, domain, (u32)((((size_t)(grow0 + row)) * k + j) * L + limb));
+  u64 a[ELL];
+  const u64 q = t.mods[limb].q;
+  const u32 sh = (u32)__clzll((long long)q);
+#pragma unroll
+  for (int s = 0; s < ELL; ++s) {
+    u64 v;
+    do { v = g.next_u64() >> sh; } while (v >= q);
+    a[s] = v;
+  }
+  const u32 trow = row0_tiled + row;
+  u64* o = M + (((size_t)(trow / R) * L + limb) * k + j) * 128 + (trow % R) * ELL;
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2)
+    *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
+}
+
+// ------------------------------------------------------------------------------------
+// samplers: one thread per polynomial, coefficient order and word consumption as the
+// reference's samplers (src/sampling/uniform.rs).  out [count][l] i64.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sample_kernel(i64* __restrict__ out, ChaChaKey key, u32 l,
+                                                     SampleJob j0, SampleJob j1, SampleJob j2) {
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  SampleJob job;
+  u32 local;
+  if (tid < j0.count) { job = j0; local = tid; }
+  else if (tid < j0.count + j1.count) { job = j1; local = tid - j0.count; }
+  else if (tid < j0.count + j1.count + j2.count) { job = j2; local = tid - j0.count - j1.count; }
+  else return;
+  ChaChaRng g;
+  g.init(key, job.domain, job.index0 + local);
+  i64* o = out + ((size_t)job.out_poly0 + local) * l;
+  auto emit = [o](u32 s, i64 v) { o[s] = v; };
+  if (job.kind == SAMPLE_CBD) sample_cbd_poly(g, l, job.cbd_half != 0, job.cbd_v, emit);
+  else sample_uniform_poly(g, l, job.bound, emit);
+}
+
+// truncated discrete Gaussian (src/sampling/normal.rs:136-190): one thread per sample.
+__device__ __forceinline__ double unit_f64(ChaChaRng& g) {
+  return (double)(g.next_u64() >> 11) * (1.0 / 9007199254740992.0);
+}
+__global__ __launch_bounds__(64) void gaussian_kernel(i64* __restrict__ out, ChaChaKey key,
+                                                       u32 index0, u32 count, u64 bound) {
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= count) return;
+  ChaChaRng g;
+  g.init(key, DOM_GAUSS, index0 + tid);
+  if (bound == 0) { out[tid] = 0; return; }            // normal.rs:137-139
+  const double bf = (double)bound;
+  if (bf > 1e15) {                                      // :144-149
+    const i64 sign = (g.next_u32() >> 31) ? 1 : -1;
+    out[tid] = sign * (i64)(g.next_u32() % 1000001u);
+    return;
+  }
+  const double sigma = bf / 16.96;                      // :8,:151
+  double ratio = 0.0;
+  bool have = false;
+  if (sigma > 0.3) {                                    // :168-170
+    ratio = 2.0 * unit_f64(g) - 1.0;
+    have = true;
+  } else {
+    for (int it = 0; it < 1000 && !have; ++it) {        // :173-179
+      const double eps = 2.220446049250313e-16;
+      const double u1 = eps + (1.0 - eps) * unit_f64(g);
+      const double u2 = unit_f64(g);
+      const double z = sqrt(-2.0 * log(u1)) * cos(2.0 * 3.14159265358979323846 * u2);  // :186-190
+      const double r = z * sigma;
+      if (r >= -1.0 && r <= 1.0) { ratio = r; have = true; }
+    }
+    if (!have) ratio = 2.0 * unit_f64(g) - 1.0;         // :182
+  }
+  const double fx = ratio * bf;                         // ratio_to_bigint fast path :199-204
+  i64 x = (i64)floor(fabs(fx) + 0.5);
+  if (fx < 0) x = -x;
+  const i64 b = (i64)bound;
+  out[tid] = x > b ? b : (x < -b ? -b : x);             // :156-160
+}
+
+// ------------------------------------------------------------------------------------
+// decrypt_mac: noisy[d] = sum_j shat[j] (.) c1s[d][j] - c2col[d]   (decryption.rs:257-274)
+// on the ciphertext layout as it arrives, [d][j][L][l].  One workgroup per dealer; thread
+// (g, e) owns slot pair e of the polynomial and the j = g, g+c, g+2c, ... terms.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void decrypt_mac_kernel(const u64* __restrict__ c1s,
+                                                            const u64* __restrict__ shat,
+                                                            const u64* __restrict__ c2col,
+                                                            u64* __restrict__ noisy,
+                                                            const Mod* __restrict__ mods, u32 k,
+                                                            u32 ell, u32 pairs, u32 c,
+                                                            u32 pair0_step) {
+  extern __shared__ v2u64 dl[];
+  const u32 d = blockIdx.x;
+  const u32 pair_base = blockIdx.y * pair0_step;
+  const u32 chunk = (pairs - pair_base) < pair0_step ? (pairs - pair_base) : pair0_step;
+  const u32 g = threadIdx.x / chunk, el = threadIdx.x % chunk;
+  const bool active = threadIdx.x < c * chunk;
+  const u32 e = pair_base + el;
+  const v2u64* cp = reinterpret_cast<const v2u64*>(c1s) + (size_t)d * k * pairs + e;
+  const v2u64* sp = reinterpret_cast<const v2u64*>(shat) + e;
+  Acc a0, a1;
+  acc_zero(a0);
+  acc_zero(a1);
+  if (active) {
+    u32 j = g;
+    for (; j + 3 * c < k; j += 4 * c) {
+      v2u64 x0 = __builtin_nontemporal_load(cp + (size_t)j * pairs);
+      v2u64 x1 = __builtin_nontemporal_load(cp + (size_t)(j + c) * pairs);
+      v2u64 x2 = __builtin_nontemporal_load(cp + (size_t)(j + 2 * c) * pairs);
+      v2u64 x3 = __builtin_nontemporal_load(cp + (size_t)(j + 3 * c) * pairs);
+      v2u64 y0 = sp[(size_t)j * pairs], y1 = sp[(size_t)(j + c) * pairs];
+      v2u64 y2 = sp[(size_t)(j + 2 * c) * pairs], y3 = sp[(size_t)(j + 3 * c) * pairs];
+      acc_mac_dev(a0, x0.x, y0.x); acc_mac_dev(a1, x0.y, y0.y);
+      acc_mac_dev(a0, x1.x, y1.x); acc_mac_dev(a1, x1.y, y1.y);
+      acc_mac_dev(a0, x2.x, y2.x); acc_mac_dev(a1, x2.y, y2.y);
+      acc_mac_dev(a0, x3.x, y3.x); acc_mac_dev(a1, x3.y, y3.y);
+    }
+    for (; j < k; j += c) {
+      v2u64 x0 = cp[(size_t)j * pairs];
+      v2u64 y0 = sp[(size_t)j * pairs];
+      acc_mac_dev(a0, x0.x, y0.x); acc_mac_dev(a1, x0.y, y0.y);
+    }
+  }
+  const u32 limb = active ? (2 * e) / ell : 0;
+  const Mod m = mods[limb];
+  v2u64 part;
+  part.x = acc_reduce(a0, m);
+  part.y = acc_reduce(a1, m);
+  if (active) dl[threadIdx.x] = part;
+  __syncthreads();
+  if (active && g == 0) {
+    v2u64 s = part;
+    for (u32 w = 1; w < c; ++w) {
+      v2u64 t = dl[w * chunk + el];
+      s.x = addmod(s.x, t.x, m.q);
+      s.y = addmod(s.y, t.y, m.q);
+    }
+    const size_t o = (size_t)d * pairs + e;
+    v2u64 c2 = reinterpret_cast<const v2u64*>(c2col)[o];
+    s.x = submod(s.x, c2.x, m.q);
+    s.y = submod(s.y, c2.y, m.q);
+    reinterpret_cast<v2u64*>(noisy)[o] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------
+#define PVW_DISPATCH_ELL(ell, ...)                       \
+  switch (ell) {                                         \
+    case 8:  { constexpr int E = 8;  __VA_ARGS__; } break;   \
+    case 16: { constexpr int E = 16; __VA_ARGS__; } break;   \
+    case 32: { constexpr int E = 32; __VA_ARGS__; } break;   \
+    case 64: { constexpr int E = 64; __VA_ARGS__; } break;   \
+    default: return hipErrorInvalidValue;                \
+  }
+
+hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat,
+                           const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s) {
+  const u32 R = 128 / ell;
+  MacSection sa = a, sb = b;
+  sa.row_blocks = (sa.nrows + R - 1) / R;
+  sb.row_blocks = (sb.nrows + R - 1) / R;
+  const u32 blocks = (sa.row_blocks + sb.row_blocks) * L;
+  if (blocks == 0) return hipSuccess;
+  PVW_DISPATCH_ELL(ell, mac_rows_kernel<E><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L));
+  return hipGetLastError();
+}
+
+hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t stride_poly,
+                       size_t stride_limb, u32 count, bool do_ntt, const DevTables& t, u32 L,
+                       u32 ell, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  const u32 threads = count * L;
+  PVW_DISPATCH_ELL(ell, prep_kernel<E><<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(coeffs, scalars, out, stride_poly, stride_limb, count, L,
+                                            do_ntt ? 1u : 0u, t));
+  return hipGetLastError();
+}
+
+hipError_t launch_ntt(u64* polys, size_t count, bool inverse, const DevTables& t, u32 L, u32 ell,
+                      hipStream_t s) {
+  // keep each launch below 2^31 threads
+  const size_t step = (size_t)1 << 24;
+  for (size_t off = 0; off < count; off += step) {
+    const u32 cnt = (u32)((count - off) < step ? (count - off) : step);
+    const u32 threads = cnt * L;
+    u64* p = polys + off * L * ell;
+    PVW_DISPATCH_ELL(ell, ntt_kernel<E><<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(p, cnt, L, inverse ? 1u : 0u, t));
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_tile(const u64* src, u64* M, u32 rows, u32 row0_tiled, u32 k, u32 L, u32 ell,
+                       bool ntt_first, const DevTables& t, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  const size_t threads = (size_t)rows * k * L;
+  PVW_DISPATCH_ELL(ell, tile_kernel<E><<<dim3((u32)((threads + 255) / 256)), dim3(256), 0, s>>>(src, M, rows, row0_tiled, k, L, ntt_first ? 1u : 0u, t));
+  return hipGetLastError();
+}
+
+hipError_t launch_untile(const u64* M, u64* dst, u32 rows, u32 row0_tiled, u32 k, u32 L, u32 ell,
+                         bool intt_after, const DevTables& t, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  const size_t threads = (size_t)rows * k * L;
+  PVW_DISPATCH_ELL(ell, untile_kernel<E><<<dim3((u32)((threads + 255) / 256)), dim3(256), 0, s>>>(M, dst, rows, row0_tiled, k, L, intt_after ? 1u : 0u, t));
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_uniform_tiled(u64* M, const ChaChaKey& key, u32 domain, u32 rows,
+                                     u32 row0_tiled, u32 grow0, u32 k, u32 L, u32 ell,
+                                     const DevTables& t, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  const size_t threads = (size_t)rows * k * L;
+  PVW_DISPATCH_ELL(ell, fill_uniform_tiled_kernel<E><<<dim3((u32)((threads + 255) / 256)), dim3(256), 0, s>>>(M, key, domain, rows, row0_tiled, grow0, k, L, t));
+  return hipGetLastError();
+}
+
+hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJob& j0,
+                         const SampleJob& j1, const SampleJob& j2, hipStream_t s) {
+  const u32 threads = j0.count + j1.count + j2.count;
+  if (threads == 0) return hipSuccess;
+  sample_kernel<<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(out, key, ell, j0, j1, j2);
+  return hipGetLastError();
+}
+
+hipError_t launch_gaussian(i64* out, const ChaChaKey& key, u32 index0, u32 count, u64 bound,
+                           hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  gaussian_kernel<<<dim3((count + 63) / 64), dim3(64), 0, s>>>(out, key, index0, count, bound);
+  return hipGetLastError();
+}
+
+hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col, u64* noisy,
+                              const DevTables& t, u32 k, u32 L, u32 ell, size_t dealers,
+                              hipStream_t s) {
+  if (dealers == 0) return hipSuccess;
+  const u32 pairs = L * ell / 2;
+  u32 step, c, threads, ny;
+  if (pairs <= 1024) {
+    step = pairs;
+    ny = 1;
+    c = pairs >= 256 ? 1 : 256 / pairs;
+    if (c > k) c = k;
+    threads = ((c * pairs + 63) / 64) * 64;
+  } else {
+    step = 1024;
+    ny = (pairs + 1023) / 1024;
+    c = 1;
+    threads = 1024;
+  }
+  const size_t lds = (size_t)threads * sizeof(v2u64);
+  for (size_t off = 0; off < dealers; off += 32768) {
+    const u32 nd = (u32)((dealers - off) < 32768 ? (dealers - off) : 32768);
+    decrypt_mac_kernel<<<dim3(nd, ny), dim3(threads), lds, s>>>(c1s + off * (size_t)k * L * ell, shat, c2col + off * (size_t)L * ell,
+                       noisy + off * (size_t)L * ell, t.mods, k, ell, pairs, c, step);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace pvw

@@ -1,0 +1,350 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the oracle (big-integer model + C restatement) and the committed golden fixtures.
+All comparisons are bit-exact (integer arithmetic)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import pvw_model as M
+import pvw_oracle as O
+import pvw_rs_amd as P
+from _util import EXAMPLE_MODULI, SEED, TEST_MODULI, make_system
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+
+
+def build_params(n, k, l, moduli, variance=0.5, bounds=(100, 200), shard=None):
+    b = (P.PvwParametersBuilder().set_parties(n).set_dimension(k).set_l(l).set_moduli(moduli)
+         .set_secret_variance(variance).set_error_bounds(*bounds))
+    if shard:
+        b.set_shard(*shard)
+    return b.build()
+
+
+def params_from_golden(z, shard=None):
+    return build_params(int(z["n"]), int(z["k"]), int(z["l"]), [int(q) for q in z["moduli"]],
+                        float(z["variance"]), (int(z["bound1"]), int(z["bound2"])), shard)
+
+
+def test_device_is_gfx950():
+    assert P.device_available(), "these tests need the HIP path; there is no CPU fallback"
+
+
+# ---------------------------------------------------------------- ring primitives
+@pytest.mark.parametrize("l", [8, 16, 32, 64])
+@pytest.mark.parametrize("moduli", [TEST_MODULI, M.bench_moduli(17)], ids=["test3", "bench17"])
+def test_ntt_round_trip_and_oracle(l, moduli):
+    p = build_params(3, 4, l, moduli)
+    orc = O.Oracle(moduli, l)
+    rng = np.random.default_rng(l)
+    polys = np.stack([rng.integers(0, q, size=(37, l), dtype=np.uint64) for q in moduli], axis=1)
+    fwd = p.ntt_forward(polys)
+    assert np.array_equal(fwd, orc.ntt_forward(polys))
+    assert np.array_equal(p.ntt_inverse(fwd), polys)
+    small = rng.integers(-(1 << 62), 1 << 62, size=(11, l), dtype=np.int64)
+    small[0, :4] = [0, -1, np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+    assert np.array_equal(p.from_coefficients(small, P.REPR_NTT), orc.small_to_ntt(small))
+    want_pb = np.array([[[int(c) % q for c in row] for q in moduli] for row in small], dtype=np.uint64)
+    assert np.array_equal(p.from_coefficients(small, P.REPR_POWER), want_pb)
+
+
+def test_encode_scalar_matches_model():
+    # parameters.rs:346-367 incl. negative scalars
+    p = build_params(3, 4, 8, TEST_MODULI)
+    m = M.Params(3, 4, 8, TEST_MODULI)
+    for s in (0, 1, 42, -7, (1 << 63) - 1, -(1 << 63)):
+        enc = p.encode_scalar(s, P.REPR_POWER)
+        assert p.poly_to_bigints(enc) == m.encode_scalar(s)
+        assert np.array_equal(p.ntt_inverse(p.encode_scalar(s, P.REPR_NTT)[None])[0], enc)
+
+
+# ---------------------------------------------------------------- samplers
+def test_samplers_match_oracle_and_statistics():
+    p = build_params(3, 4, 16, TEST_MODULI)
+    for var in (0.5, 1.0, 2.0, 3.0, 10.0, 16.0):
+        got = p.sample_vec_cbd(SEED, P.DOM_R, 9, 300, var)
+        assert np.array_equal(got, O.sample_cbd(SEED, M.DOM_R, 9, 300, 16, var))
+    xs = p.sample_vec_cbd(SEED, P.DOM_SK, 0, 1000, 0.5).reshape(-1)       # tests/sampling.rs:198-274
+    assert set(np.unique(xs)) <= {-1, 0, 1} and abs(xs.mean()) < 0.1 and abs(xs.var() - 0.5) < 0.1
+    for bound in (1, 50, 200, 1172385, (1 << 31) - 1, 1 << 32, (1 << 40) + 12345, 1 << 61):
+        got = p.sample_uniform_coefficients(SEED, P.DOM_E2, 3, 200, bound)
+        assert np.array_equal(got, O.sample_uniform(SEED, M.DOM_E2, 3, 200, 16, bound))
+        assert got.min() >= -bound and got.max() <= bound
+    for bad in (0.3, 0.7, 17.0):
+        with pytest.raises(P.PvwError) as e:
+            p.sample_vec_cbd(SEED, P.DOM_R, 0, 1, bad)
+        assert e.value.variant == "SamplingError"
+
+
+def test_gaussian_contract():
+    # normal.rs:136-162; tests/sampling.rs:15-195 (bounds respected, sign mix, scale ordering)
+    p = build_params(3, 4, 8, TEST_MODULI)
+    assert np.all(p.sample_discrete_gaussian_vec(SEED, 0, 64) == 0)
+    for bound in (1, 4, 100, 10 ** 6, 10 ** 12):
+        xs = p.sample_discrete_gaussian_vec(SEED, bound, 4096)
+        assert xs.min() >= -bound and xs.max() <= bound
+        if bound >= 100:
+            assert (xs > 0).any() and (xs < 0).any()
+    small = np.abs(p.sample_discrete_gaussian_vec(SEED, 4, 4096)).mean()
+    large = np.abs(p.sample_discrete_gaussian_vec(SEED, 10 ** 6, 4096)).mean()
+    assert large > small
+    # bound <= 5: sigma = bound/16.96 <= 0.3 -> genuinely Gaussian ratio, almost always rounds to 0 or +-1
+    xs = p.sample_discrete_gaussian_vec(SEED, 4, 4096)
+    assert np.abs(xs).max() <= 4 and (xs == 0).mean() > 0.3
+    # the model's stream gives the same integers for the uniform branches (no libm involved)
+    rng_vals = []
+    for i in range(32):
+        rng_vals.append(M.sample_single_gaussian(10 ** 6, M.ChaChaRng(SEED, M.DOM_GAUSS, i)))
+    assert p.sample_discrete_gaussian_vec(SEED, 10 ** 6, 32).tolist() == rng_vals
+    huge = p.sample_discrete_gaussian_vec(SEED, 10 ** 16, 256)
+    assert np.abs(huge).max() <= 10 ** 6
+    assert huge.tolist() == [M.sample_single_gaussian(10 ** 16, M.ChaChaRng(SEED, M.DOM_GAUSS, i)) for i in range(256)]
+
+
+# ---------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
+def test_golden_keygen_encrypt_decrypt(path):
+    z = np.load(path)
+    p = params_from_golden(z)
+    n, k = p.n, p.k
+    assert p.roots() == [int(x) for x in z["psi"]]
+    crs = P.PvwCrs.from_polynomials(p, z["A_pb"], P.REPR_POWER)
+    assert np.array_equal(crs.matrix(P.REPR_POWER), z["A_pb"])
+    gpk = P.GlobalPublicKey.new(crs)
+    assert not gpk.is_full() and gpk.num_public_keys() == 0
+    # keygen on the device with the fixture's secrets and key errors
+    gpk.generate_with_errors(0, z["sk"], z["ek"])
+    assert gpk.is_full() and gpk.num_public_keys() == n
+    assert np.array_equal(gpk.matrix(repr=P.REPR_POWER), z["B_pb"])
+    # encrypt with the fixture's randomness, both output representations
+    ct = P.encrypt(z["scalars"], gpk, r=z["r"], e1=z["e1"], e2=z["e2"], repr=P.REPR_POWER)
+    assert np.array_equal(ct.c1, z["c1_pb"]) and np.array_equal(ct.c2, z["c2_pb"])
+    ct_ntt = P.encrypt(z["scalars"], gpk, r=z["r"], e1=z["e1"], e2=z["e2"], repr=P.REPR_NTT)
+    assert np.array_equal(p.ntt_inverse(ct_ntt.c1), z["c1_pb"])
+    assert np.array_equal(p.ntt_inverse(ct_ntt.c2), z["c2_pb"])
+    # decrypt every party, from both representations
+    for ctx in (ct, ct_ntt):
+        for i in range(n):
+            sk = P.SecretKey.from_coefficients(p, z["sk"][i])
+            vals, noisy = P.api._decrypt_batch(p, [ctx], sk, i, return_noisy=True)
+            assert np.array_equal(noisy[0], z["noisy_pb"][i])
+            assert vals[0] == int(z["decoded"][i])
+
+
+@pytest.mark.parametrize("path", GOLDEN[:2], ids=[os.path.basename(g)[:-4] for g in GOLDEN[:2]])
+def test_golden_load_pk_paths(path):
+    # add_public_key one party at a time, in NTT form computed by the oracle, then encrypt
+    z = np.load(path)
+    p = params_from_golden(z)
+    moduli = [int(q) for q in z["moduli"]]
+    orc = O.Oracle(moduli, p.l)
+    crs = P.PvwCrs.from_polynomials(p, orc.ntt_forward(z["A_pb"]), P.REPR_NTT)
+    gpk = P.GlobalPublicKey.new(crs)
+    b_hat = orc.ntt_forward(z["B_pb"])
+    for i in reversed(range(p.n)):
+        gpk.add_public_key(i, b_hat[i], P.REPR_NTT)
+        assert gpk.num_public_keys() == p.n                      # public_key.rs:245: max index + 1
+    assert np.array_equal(gpk.get_polynomial(1, 2, P.REPR_POWER), z["B_pb"][1, 2])
+    assert gpk.get_polynomial(p.n, 0) is None
+    ct = P.encrypt(z["scalars"], gpk, r=z["r"], e1=z["e1"], e2=z["e2"], repr=P.REPR_NTT)
+    g_hat = orc.ntt_forward(z["g_pb"][None])[0]
+    c1o, c2o = orc.encrypt(orc.ntt_forward(z["A_pb"]), b_hat, g_hat, z["scalars"], z["r"], z["e1"], z["e2"])
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)   # NTT domain, same psi rule
+
+
+# ---------------------------------------------------------------- reference-shaped end-to-end tests
+def setup_system(n, k, l, moduli, variance=0.5, seed=SEED):
+    b1, b2 = P.PvwParameters.suggest_error_bounds(n, k, l, moduli, variance)
+    p = build_params(n, k, l, moduli, variance, (b1, b2))
+    parties = [P.Party.new(i, p, seed) for i in range(n)]
+    crs = P.PvwCrs.new_deterministic(p, seed)
+    gpk = P.GlobalPublicKey.new(crs)
+    gpk.generate_all_party_keys(parties, seed)
+    return p, gpk, parties
+
+
+def test_basic_encryption_shapes_and_wrappers():
+    # tests/crypto.rs:91-149
+    p, gpk, _ = setup_system(3, 4, 8, TEST_MODULI)
+    ct = P.encrypt([10, 20, 30], gpk, SEED)
+    ct.validate()
+    assert len(ct) == p.n and len(ct.c1) == p.k and len(ct.c2) == p.n
+    assert ct.get_party_ciphertext(p.n) is None and ct.get_party_ciphertext(0) is not None
+    assert len(P.encrypt_party_shares([10000, 20000, 30000], 1, gpk, SEED)) == 3
+    cts = P.encrypt_all_party_shares([[11, 12, 13], [21, 22, 23], [31, 32, 33]], gpk, SEED)
+    assert len(cts) == 3 and all(len(c) == 3 for c in cts)
+    assert not np.array_equal(cts[0].c1, cts[1].c1)            # every dealer has its own randomness
+    assert len(P.encrypt_broadcast(999, gpk, SEED)) == 3
+    # determinism: same seed, same ciphertext
+    assert np.array_equal(P.encrypt([10, 20, 30], gpk, SEED).c2, ct.c2)
+
+
+def test_invalid_inputs():
+    # tests/crypto.rs:181-207
+    p, gpk, _ = setup_system(3, 4, 8, TEST_MODULI)
+    for bad in ([1, 2], [1, 2, 3, 4]):
+        with pytest.raises(P.PvwError) as e:
+            P.encrypt(bad, gpk, SEED)
+        assert e.value.variant == "InvalidParameters" and "Must provide exactly n=3 scalars" in str(e.value)
+    with pytest.raises(P.PvwError):
+        P.encrypt_party_shares([1, 2, 3], 999, gpk, SEED)
+    with pytest.raises(P.PvwError):
+        P.encrypt_all_party_shares([[1, 2], [3, 4, 5], [6, 7, 8]], gpk, SEED)
+    with pytest.raises(P.PvwError):
+        P.Party.new(3, p, SEED)                                   # tests/keys.rs:53-64
+    # incomplete global key (encryption.rs:117-121)
+    p2 = build_params(3, 4, 8, TEST_MODULI)
+    crs = P.PvwCrs.new_deterministic(p2, SEED)
+    gpk2 = P.GlobalPublicKey.new(crs)
+    gpk2.generate_and_add_party(P.Party.new(0, p2, SEED), SEED)
+    with pytest.raises(P.PvwError) as e:
+        P.encrypt([1, 2, 3], gpk2, SEED)
+    assert "not complete" in str(e.value)
+    # failing correctness gate (encryption.rs:124-128)
+    p3 = build_params(3, 4, 8, [0xFFFFEE001], 0.5, (1 << 50, 1 << 50))
+    gpk3 = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p3, SEED))
+    gpk3.fill_uniform(SEED)
+    with pytest.raises(P.PvwError) as e:
+        P.encrypt([1, 2, 3], gpk3, SEED)
+    assert "correctness condition" in str(e.value)
+    with pytest.raises(P.PvwError):
+        P.decrypt_party_shares([], P.SecretKey.random(p, SEED, 0), 0)
+
+
+@pytest.mark.parametrize("n,k,l,moduli,variance", [
+    (10, 4, 16, TEST_MODULI, 0.5),        # tests/crypto.rs:237-305 test_decryption_l16
+    (7, 32, 8, TEST_MODULI, 0.5),         # examples/pvw_valid_dec.rs commented config
+    (5, 64, 8, EXAMPLE_MODULI, 10.0),     # examples/pvw_valid_dec.rs:40-52 at reduced k
+])
+def test_decryption_round_trip(n, k, l, moduli, variance):
+    if variance == 10.0:
+        p = build_params(n, k, l, moduli, variance, (1, 1172385))
+        parties = [P.Party.new(i, p, SEED) for i in range(n)]
+        gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+        gpk.generate_all_party_keys(parties, SEED)
+    else:
+        p, gpk, parties = setup_system(n, k, l, moduli, variance)
+    all_vectors = [[dealer * 100 + j for j in range(1, n + 1)] for dealer in range(n)]
+    cts = P.encrypt_all_party_shares(all_vectors, gpk, SEED)
+    correct = total = 0
+    for idx, party in enumerate(parties):
+        shares = P.decrypt_party_shares(cts, party.secret_key, idx)
+        for dealer, v in enumerate(shares):
+            correct += v == all_vectors[dealer][idx]
+            total += 1
+        assert P.decrypt_party_value(cts[0], party.secret_key, idx) == shares[0]
+    assert correct / total >= 0.95
+
+
+def test_seed_mode_equals_explicit_mode_with_oracle_samples():
+    n, k, l, moduli = 12, 8, 16, M.bench_moduli(5)
+    p = build_params(n, k, l, moduli, 3.0, (77, 1 << 33))
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    scalars = [(i * 1000 + 1) % (1 << 32) for i in range(n)]
+    ct = P.encrypt(scalars, gpk, SEED)
+    r = O.sample_cbd(SEED, M.DOM_R, 0, k, l, 3.0)
+    e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 77)
+    e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 1 << 33)
+    ct2 = P.encrypt(scalars, gpk, r=r, e1=e1, e2=e2)
+    assert np.array_equal(ct.c1, ct2.c1) and np.array_equal(ct.c2, ct2.c2)
+    # and both equal the C oracle on the same synthetic A-hat / B-hat
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(SEED, M.DOM_CRS, 0, k * k).reshape(k, k, len(moduli), l)
+    b_hat = orc.fill_uniform(SEED, M.DOM_PK, 0, n * k).reshape(n, k, len(moduli), l)
+    assert np.array_equal(gpk.crs.matrix(P.REPR_NTT), a_hat)
+    assert np.array_equal(gpk.matrix(repr=P.REPR_NTT), b_hat)
+    g_hat = p.gadget_polynomial(P.REPR_NTT)
+    c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, np.array(scalars, dtype=np.uint64), r, e1, e2)
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+
+
+@pytest.mark.parametrize("n,k,l,L", [
+    (33, 7, 8, 3),        # ragged: k not a multiple of 4, n not a multiple of the tile rows
+    (5, 1, 8, 2),         # k = 1 (tests/params.rs:253)
+    (19, 130, 16, 4),     # k > one staged chunk per wave
+    (9, 300, 32, 2),      # l = 32, several r-hat chunks
+    (6, 24, 64, 2),       # l = 64
+    (1, 5, 8, 1),         # single party, single limb
+])
+def test_ragged_geometries_against_c_oracle(n, k, l, L):
+    moduli = M.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    scalars = [(i * 1000 + 1) % (1 << 32) for i in range(n)]
+    ct = P.encrypt(scalars, gpk, SEED)
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(SEED, M.DOM_CRS, 0, k * k).reshape(k, k, L, l)
+    b_hat = orc.fill_uniform(SEED, M.DOM_PK, 0, n * k).reshape(n, k, L, l)
+    r = O.sample_cbd(SEED, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
+    e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
+    c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), np.array(scalars, dtype=np.uint64), r, e1, e2)
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+    # batched decrypt of D copies against the C oracle (noisy polynomials, power basis)
+    sk = O.sample_cbd(SEED, M.DOM_SK, 0, k, l, 0.5)
+    D = 5
+    c1s = np.stack([np.roll(ct.c1, d, axis=0) for d in range(D)])
+    c2col = np.stack([ct.c2[d % n] for d in range(D)])
+    cts = [P.PvwCiphertext(c1s[d], np.repeat(c2col[d][None], n, axis=0), p, P.REPR_NTT) for d in range(D)]
+    vals, noisy = P.api._decrypt_batch(p, cts, P.SecretKey.from_coefficients(p, sk), 0, return_noisy=True)
+    assert np.array_equal(noisy, orc.decrypt_noisy(sk, c1s, c2col))
+
+
+def test_sharded_contexts_match_unsharded():
+    # one process per GPU holds rows [party_lo, party_hi) of B and [c1_lo, c1_hi) of A
+    n, k, l, moduli = 21, 12, 8, M.bench_moduli(3)
+    full = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(full, SEED))
+    gpk.fill_uniform(SEED)
+    scalars = [(i * 1000 + 1) % (1 << 32) for i in range(n)]
+    ct = P.encrypt(scalars, gpk, SEED)
+    c1 = np.zeros_like(ct.c1)
+    c2 = np.zeros_like(ct.c2)
+    world = 3
+    for rank in range(world):
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        clo, chi = k * rank // world, k * (rank + 1) // world
+        ps = build_params(n, k, l, moduli, shard=(lo, hi, clo, chi))
+        g = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(ps, SEED))
+        g.fill_uniform(SEED)
+        assert g.is_full()
+        part = P.encrypt(scalars, g, SEED)
+        assert not part.c1[:clo].any() and not part.c2[:lo].any()
+        c1[clo:chi] = part.c1[clo:chi]
+        c2[lo:hi] = part.c2[lo:hi]
+    assert np.array_equal(c1, ct.c1) and np.array_equal(c2, ct.c2)
+
+
+def test_config2_full_size_against_c_oracle():
+    # BASELINE.json configs[1]: n=1024, k=256, l=8, 17 limbs (1037-bit Q), bit-exact vs the CPU path
+    n, k, l, L = 1024, 256, 8, 17
+    moduli = M.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, bytes([0xA]) * 32))
+    gpk.fill_uniform(bytes([0xB]) * 32)
+    scalars = np.array([(i * 1000 + 1) % (1 << 32) for i in range(n)], dtype=np.uint64)
+    ct = P.encrypt(scalars, gpk, SEED)
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(bytes([0xA]) * 32, M.DOM_CRS, 0, k * k).reshape(k, k, L, l)
+    b_hat = orc.fill_uniform(bytes([0xB]) * 32, M.DOM_PK, 0, n * k).reshape(n, k, L, l)
+    r = O.sample_cbd(SEED, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
+    e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
+    c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), scalars, r, e1, e2)
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+    # linearity property at full size: Enc(m; r,e) - Enc(m'; r,e) = (m - m') * g, limb-wise
+    ct2 = P.encrypt(scalars + np.uint64(5), gpk, SEED, repr=P.REPR_POWER)
+    ct1 = P.encrypt(scalars, gpk, SEED, repr=P.REPR_POWER)
+    g = p.gadget_polynomial(P.REPR_POWER)
+    for i, q in enumerate(moduli):
+        diff = (ct2.c2[:, i].astype(object) - ct1.c2[:, i].astype(object)) % q
+        want = (5 * g[i].astype(object)) % q
+        assert (diff == want[None, :]).all()
+    assert np.array_equal(ct1.c1, ct2.c1)

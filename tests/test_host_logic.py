@@ -1,0 +1,134 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every
+symbol include/pvw_hip.h declares, parameter arithmetic / validation / decode agree with the
+oracle and the golden fixtures.  No device compute is called here."""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pvw_model as M
+import pvw_rs_amd as P
+from pvw_rs_amd import _ffi
+from _util import TEST_MODULI, EXAMPLE_MODULI
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "pvw_hip.h")).read()
+    declared = re.findall(r"^PVW_API int32_t (pvw_\w+)\(", header, flags=re.M)
+    assert len(declared) >= 40
+    lib = _ffi.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"libpvw_hip.so does not export {name}"
+    assert set(declared) == set(_ffi._SIGNATURES), "ctypes table and header disagree"
+
+
+def test_error_codes_follow_pvw_error_order():
+    header = open(os.path.join(ROOT, "include", "pvw_hip.h")).read()
+    codes = dict((int(v), k) for k, v in re.findall(r"(PVW_ERR_\w+) = (\d+)", header))
+    assert len(codes) == 19 and codes[1] == "PVW_ERR_INVALID_PARAMETERS" and codes[19] == "PVW_ERR_INTERNAL"
+    assert _ffi.ERROR_NAMES[15] == "DimensionMismatch" and _ffi.ERROR_NAMES[16] == "IndexOutOfBounds"
+
+
+def _builder(n=3, k=4, l=8, moduli=TEST_MODULI):
+    return P.PvwParametersBuilder().set_parties(n).set_dimension(k).set_l(l).set_moduli(moduli)
+
+
+def test_builder_validation_and_defaults():
+    # parameters.rs:117-195; tests/params.rs:677-697; tests/keys.rs:541-576
+    p = _builder().build()
+    assert (p.secret_variance, p.error_bound_1, p.error_bound_2, p.t) == (0.5, 100, 200, 1)
+    for bad in (_builder(n=0), _builder(k=0), _builder(l=4), _builder(l=12), _builder(moduli=[]),
+                _builder(moduli=[0xFFFFEE001, 0xFFFFEE001]), _builder(moduli=[15]), _builder(moduli=[(1 << 62) + 1]),
+                _builder(moduli=[41]),                    # prime but not 1 mod 16
+                _builder().set_error_bounds_u32(0, 5), _builder().set_error_bounds_u32(5, 0)):
+        with pytest.raises(P.PvwError) as e:
+            bad.build()
+        assert e.value.variant == "InvalidParameters"
+    with pytest.raises(P.PvwError):
+        P.PvwParametersBuilder().set_parties(3).build()     # k not set
+
+
+@pytest.mark.parametrize("l,moduli", [(8, TEST_MODULI), (16, TEST_MODULI), (32, TEST_MODULI), (8, EXAMPLE_MODULI),
+                                      (8, M.bench_moduli(17)), (16, M.bench_moduli(34))])
+def test_delta_gadget_roots_match_model(l, moduli):
+    p = _builder(l=l, moduli=moduli).build()
+    m = M.Params(3, 4, l, moduli)
+    assert p.q_total() == m.Q and p.delta() == m.delta and p.delta_power_l_minus_1() == m.delta_power_l_minus_1
+    assert p.roots() == [M.minimal_primitive_root(q, 2 * l) for q in moduli]
+    g = p.gadget_polynomial(P.REPR_POWER)
+    assert p.poly_to_bigints(g) == m.gadget_vector()            # tests/crypto.rs:17-37
+    # NTT-domain gadget = evaluation of the gadget at psi^(2 bitrev(s)+1)
+    ghat = p.gadget_polynomial(P.REPR_NTT)
+    for i, q in enumerate(moduli[:3]):
+        assert ghat[i].tolist() == M.ntt_eval([int(v) for v in g[i]], q, p.roots()[i])
+    assert p.verify_correctness_condition() == m.verify_correctness_condition()
+
+
+def test_correctness_gate_and_suggested_bounds():
+    for (n, k, l) in [(3, 4, 8), (10, 4, 16), (30, 64, 32), (5, 1024, 8)]:
+        assert P.PvwParameters.suggest_error_bounds(n, k, l, TEST_MODULI, 0.5) == \
+            M.Params.suggest_error_bounds(n, k, l, TEST_MODULI, 0.5)
+    # failing gate: huge bounds on a small modulus (tests/crypto.rs:209-234 shape)
+    p = _builder(moduli=[0xFFFFEE001]).set_error_bounds((1 << 50), (1 << 50)).build()
+    assert not p.verify_correctness_condition()
+    assert not M.Params(3, 4, 8, [0xFFFFEE001], 0.5, 1 << 50, 1 << 50).verify_correctness_condition()
+    with pytest.raises(P.PvwError):
+        P.PvwParameters.suggest_error_bounds(1 << 26, 1 << 12, 8, [0xFFFFEE001], 0.5)
+    with pytest.raises(M.PvwError):
+        M.Params.suggest_error_bounds(1 << 26, 1 << 12, 8, [0xFFFFEE001], 0.5)
+
+
+def test_set_roots_validation():
+    p = _builder().build()
+    with pytest.raises(P.PvwError):
+        p.set_roots([1, 1, 1])
+    alt = []
+    for q, psi in zip(TEST_MODULI, p.roots()):
+        alt.append(pow(psi, 3, q))                               # another primitive 16th root
+    p.set_roots(alt)
+    assert p.roots() == alt
+    g = p.gadget_polynomial(P.REPR_POWER)
+    ghat = p.gadget_polynomial(P.REPR_NTT)
+    assert ghat[0].tolist() == M.ntt_eval([int(v) for v in g[0]], TEST_MODULI[0], alt[0])
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
+def test_decode_matches_golden(path):
+    z = np.load(path)
+    p = (P.PvwParametersBuilder().set_parties(int(z["n"])).set_dimension(int(z["k"])).set_l(int(z["l"]))
+         .set_moduli([int(q) for q in z["moduli"]]).set_secret_variance(float(z["variance"]))
+         .set_error_bounds(int(z["bound1"]), int(z["bound2"])).build())
+    assert p.delta() == sum(int(w) << (64 * i) for i, w in enumerate(z["delta_words"]))
+    assert P.decode_scalar_pvw(p, z["noisy_pb"]) == [int(v) for v in z["decoded"]]
+
+
+def test_decode_quirks_match_model():
+    # decryption.rs:226-247: small negatives -> 0, big negatives -> 0, >= 2^64 -> 0
+    rng = np.random.default_rng(7)
+    for l, moduli in [(8, TEST_MODULI), (16, M.bench_moduli(34))]:
+        p = _builder(l=l, moduli=moduli).build()
+        m = M.Params(3, 4, l, moduli)
+        cases = []
+        for msg in (0, 1, 12345, -5, -1000, -1001, -5000, (1 << 63) - 1, (1 << 64) - 1, 1 << 64, (1 << 70) + 3):
+            noise = [int(x) for x in rng.integers(-300, 300, size=l)]
+            cases.append([(-(msg * m.delta ** j) + noise[j]) % m.Q for j in range(l)])
+        for _ in range(20):   # random garbage polynomials must decode identically as well
+            cases.append([int.from_bytes(rng.bytes(m.Q.bit_length() // 8 + 8), "little") % m.Q for _ in range(l)])
+        arr = np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64)
+        assert P.decode_scalar_pvw(p, arr) == [M.decode_scalar_pvw(z, m) for z in cases]
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    if P.device_available():
+        pytest.skip("GPU present")
+    p = _builder().build()
+    with pytest.raises(P.PvwError) as e:
+        P.PvwCrs.new_deterministic(p, bytes(32))
+    assert e.value.variant == "InternalError" and "no CPU fallback" in str(e.value)
+    with pytest.raises(P.PvwError):
+        p.ntt_forward(np.zeros((1, 3, 8), dtype=np.uint64))
