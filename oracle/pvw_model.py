@@ -331,7 +331,7 @@ def chacha_block(key_words: Sequence[int], counter: int, stream: int, rounds: in
 
 
 # stream-id domains: stream = (domain << 32) | polynomial index
-DOM_R, DOM_E1, DOM_E2, DOM_SK, DOM_EKEY, DOM_CRS, DOM_GAUSS = 0, 1, 2, 3, 4, 5, 6
+DOM_R, DOM_E1, DOM_E2, DOM_SK, DOM_EKEY, DOM_CRS, DOM_GAUSS, DOM_PK = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class ChaChaRng:

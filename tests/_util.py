@@ -9,6 +9,16 @@ EXAMPLE_MODULI = [0x800000022A0001, 0x800000021A0001, 0x80000002120001, 0x800000
 SEED = bytes([0x2A]) * 32                                         # tests/params.rs:91
 
 
+def primes_1mod(step, count, top=(1 << 61)):
+    """`count` primes p = 1 (mod step) descending from `top` (for ring degrees l > 32)."""
+    out, p = [], top + 1
+    while len(out) < count:
+        p -= step
+        if M.is_prime(p):
+            out.append(p)
+    return out
+
+
 def ring_to_rns(poly_ints, moduli):
     """list of l ints mod Q -> [L][l] u64"""
     return np.array([[c % q for c in poly_ints] for q in moduli], dtype=np.uint64)
