@@ -30,8 +30,28 @@ CONFIGS = {
     "c3": (4096, 256, 8, 17, "BASELINE configs[2] / north-star target: n=4096, k=256, l=8, 1037-bit q (17 limbs)"),
     "c4shard": (2048, 512, 16, 34, "BASELINE configs[3] per-GPU shard: n=16384/8, k=512, l=16, 2074-bit q"),
 }
+DECRYPT_CONFIGS = {
+    # name: (dealers per GPU, k, l, limbs, description)
+    "c5shard": (1024, 512, 16, 34, "BASELINE configs[4] per-GPU shard: D=8192/8 dealer ciphertexts, k=512, l=16, 2074-bit q"),
+    "d3": (2048, 256, 8, 17, "decrypt of D=2048 dealer ciphertexts at the config-3 geometry: k=256, l=8, 1037-bit q"),
+}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SEED_A, SEED_B, SEED_ENC = bytes([0xA]) * 32, bytes([0xB]) * 32, bytes([0x2A]) * 32
+
+
+def measured_traffic(config, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/r*_<config>_summary.json, written by tools/summarize_prof.py), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_summary.json"))):
+        try:
+            for name, kv in json.load(open(f))["kernels"].items():
+                if name.startswith(kernel_prefix) and "hbm_traffic_bytes_per_launch" in kv:
+                    best = (kv["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
 
 
 def main():
@@ -39,7 +59,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS) + sorted(DECRYPT_CONFIGS))
+    ap.add_argument("--path", default="encrypt", choices=["encrypt", "decrypt"],
+                    help="encrypt = the headline metric; decrypt = batched decrypt_party_value (BASELINE configs[4] shape)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -67,7 +89,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    n_per, k, l, L, desc = CONFIGS[args.config]
+    if args.path == "decrypt":
+        return bench_decrypt(args, world, rank, local_rank, dev)
+    n_per, k, l, L, desc = CONFIGS[args.config or "c3"]
     n_total = n_per * world
     moduli = M.bench_moduli(L)
     lo, hi = rank * n_per, (rank + 1) * n_per
@@ -143,7 +167,7 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    kt = {name: params.kernel_time(name) for name in ("mac_rows", "sample", "prep")}
+    kt = {name: params.kernel_time(name) for name in ("mac_rows", "prologue")}
     params.set_profiling(False)
     mac_ms, mac_launches = kt["mac_rows"]
     mac_avg_s = mac_ms / max(mac_launches, 1) * 1e-3
@@ -152,6 +176,7 @@ def main():
     alg_bytes = 8 * L * l * (n_per * k + rows_a * k + n_per + rows_a + k)
     achieved = alg_bytes / mac_avg_s / 1e9 if mac_avg_s > 0 else 0.0
 
+    tr = measured_traffic(args.config or "c3", "mac_rows_kernel")
     out = {
         "metric": "parties/s for n-party encrypt (pvw::crypto::encrypt); achieved HBM GB/s vs peak",
         "value": value, "unit": "parties/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,7 +186,8 @@ def main():
                    "rns_limbs": L, "q_bits": int(params.q_total().bit_length()), "randomness": "seed (ChaCha8), on device",
                    "sharding": f"party-sharded x{world}, A-hat broadcast once, no data-path collective"},
         "roofline": {"bound": "hbm", "kernel": "mac_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+                     "traffic_source": (tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)") if tr else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": mac_avg_s * 1e6,
                      "launches_timed": mac_launches},
         "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},
@@ -195,6 +221,97 @@ def main():
                       f"OpenMP over parties, c1 loop serial as in crs.rs:188; {t_cpu:.1f} s of CPU work",
             "bit_exact_vs_gpu": same,
         }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def bench_decrypt(args, world, rank, local_rank, dev):
+    """Batched decrypt_party_value (decryption.rs:249-278) of D dealer ciphertexts per GPU for one
+    secret key: dealers are sharded over the ranks, nothing is exchanged on the data path (the
+    D x u64 results would be all-gathered by the caller)."""
+    import numpy as np
+    import torch
+
+    import pvw_model as M
+    import pvw_rs_amd as P
+    from pvw_rs_amd import _ffi
+
+    D, k, l, L, desc = DECRYPT_CONFIGS[args.config or "c5shard"]
+    moduli = M.bench_moduli(L)
+    params = (P.PvwParametersBuilder().set_parties(D * world).set_dimension(k).set_l(l).set_moduli(moduli)
+              .set_device(local_rank).build())
+    h, lib = params._h, _ffi.lib()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    qmin = int(min(moduli))
+    c1s = torch.randint(0, qmin, (D, k, L, l), dtype=torch.int64, device=dev, generator=g)
+    c2col = torch.randint(0, qmin, (D, L, l), dtype=torch.int64, device=dev, generator=g)
+    noisy = torch.zeros((D, L, l), dtype=torch.int64, device=dev)
+    sk_host = params.sample_vec_cbd(SEED_ENC, P.DOM_SK, 0, k)
+    sk = torch.from_numpy(sk_host).to(dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        rc = lib.pvw_decrypt_noisy_device(h, C.c_void_p(sk.data_ptr()), C.c_void_p(c1s.data_ptr()),
+                                          C.c_void_p(c2col.data_ptr()), D, P.REPR_NTT,
+                                          C.c_void_p(noisy.data_ptr()), stream)
+        if rc != 0:
+            raise RuntimeError(_ffi.last_error())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    params.set_profiling(True)
+    params.reset_profiling()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    kt = {name: params.kernel_time(name) for name in ("decrypt_mac", "prep", "intt")}
+    params.set_profiling(False)
+    mac_ms, launches = kt["decrypt_mac"]
+    avg_s = mac_ms / max(launches, 1) * 1e-3
+    alg_bytes = 8 * L * l * (D * k + D + D + k)      # c1s + c2col reads, noisy write, s-hat read (SURVEY 8d, C5)
+    achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    # host decode of the D noisy polynomials (decryption.rs:10-58), timed separately
+    nz = noisy.cpu().numpy().view(np.uint64)
+    t1 = time.perf_counter()
+    vals = P.decode_scalar_pvw(params, nz)
+    t_dec = time.perf_counter() - t1
+    tr = measured_traffic(args.config or "c5shard", "decrypt_mac_kernel")
+    out = {
+        "metric": "dealer ciphertexts/s for batched decrypt_party_value (device part: <sk,c1> - c2, INTT)",
+        "value": D * world * args.steps / elapsed, "unit": "ciphertexts/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": desc, "dealers_per_gpu": D, "k": k, "l": l, "rns_limbs": L,
+                   "q_bits": int(params.q_total().bit_length())},
+        "roofline": {"bound": "hbm", "kernel": "decrypt_mac_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6, "launches_timed": launches},
+        "kernel_ms_per_step": {name: v[0] / max(args.steps, 1) for name, v in kt.items()},
+        "host_decode": {"seconds": t_dec, "ciphertexts": D, "note": "integer gadget decode on host cores, outside the timed region"},
+        "sample_values": [int(x) for x in vals[:4]],
+    }
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

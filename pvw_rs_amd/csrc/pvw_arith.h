@@ -62,6 +62,13 @@ PVW_HD u64 mulmod(u64 a, u64 b, const Mod& m) {
   u128 p = (u128)a * b;
   return reduce128((u64)p, (u64)(p >> 64), m);
 }
+// Shoup / Harvey multiplication by a fixed w < q with wp = floor(w * 2^64 / q):
+// a*w - hi64(a*wp)*q lies in [0, 2q) for ANY 64-bit a.  Used for every twiddle / table multiply.
+PVW_HD u64 mulmod_shoup(u64 a, u64 w, u64 wp, u64 q) {
+  u64 r = a * w - mulhi64(a, wp) * q;
+  return r >= q ? r - q : r;
+}
+inline u64 shoup_precompute(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
 PVW_HD u64 addmod(u64 a, u64 b, u64 q) {
   u64 s = a + b;
   return s >= q ? s - q : s;
@@ -72,7 +79,7 @@ PVW_HD u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
 // the rule Poly::from_coefficients(&[i64]) follows as well, tests/params.rs:733-767)
 PVW_HD u64 signed_residue(i64 c, const Mod& m) {
   u64 a = c < 0 ? (u64)0 - (u64)c : (u64)c;
-  u64 r = reduce128(a, 0, m);
+  u64 r = a < m.q ? a : reduce128(a, 0, m);   // small coefficients (the common case) need no reduction
   return (c < 0 && r != 0) ? m.q - r : r;
 }
 
@@ -168,19 +175,20 @@ PVW_HD u32 bitrev32(u32 i, u32 bits) {
 
 // ---------------------------------------------------------------- l-point negacyclic NTT
 // In-register transform of one limb, L_ a compile-time 8/16/32/64: natural order in,
-// bit-reversed order out (slot s holds a(psi^(2*bitrev(s)+1))).  tw[i] = psi^bitrev(i).
+// bit-reversed order out (slot s holds a(psi^(2*bitrev(s)+1))).  tw[i] = psi^bitrev(i),
+// twp[i] = floor(tw[i]*2^64/q) (Shoup).
 template <int L_>
-PVW_HD void ntt_forward(u64 (&a)[L_], const u64* tw, const Mod& m) {
+PVW_HD void ntt_forward(u64 (&a)[L_], const u64* tw, const u64* twp, const Mod& m) {
   int step = L_;
 #pragma unroll
   for (int mm = 1; mm < L_; mm <<= 1) {
     step >>= 1;
 #pragma unroll
     for (int i = 0; i < mm; ++i) {
-      u64 w = tw[mm + i];
+      u64 w = tw[mm + i], wp = twp[mm + i];
 #pragma unroll
       for (int j = 2 * i * step; j < 2 * i * step + step; ++j) {
-        u64 u = a[j], v = mulmod(a[j + step], w, m);
+        u64 u = a[j], v = mulmod_shoup(a[j + step], w, wp, m.q);
         a[j] = addmod(u, v, m.q);
         a[j + step] = submod(u, v, m.q);
       }
@@ -189,24 +197,24 @@ PVW_HD void ntt_forward(u64 (&a)[L_], const u64* tw, const Mod& m) {
 }
 // inverse: bit-reversed in, natural out; itw[i] = psi^-bitrev(i); linv = l^-1
 template <int L_>
-PVW_HD void ntt_inverse(u64 (&a)[L_], const u64* itw, u64 linv, const Mod& m) {
+PVW_HD void ntt_inverse(u64 (&a)[L_], const u64* itw, const u64* itwp, u64 linv, u64 linvp, const Mod& m) {
   int step = 1;
 #pragma unroll
   for (int mm = L_ >> 1; mm >= 1; mm >>= 1) {
 #pragma unroll
     for (int i = 0; i < mm; ++i) {
-      u64 w = itw[mm + i];
+      u64 w = itw[mm + i], wp = itwp[mm + i];
 #pragma unroll
       for (int j = 2 * i * step; j < 2 * i * step + step; ++j) {
         u64 u = a[j], v = a[j + step];
         a[j] = addmod(u, v, m.q);
-        a[j + step] = mulmod(submod(u, v, m.q), w, m);
+        a[j + step] = mulmod_shoup(submod(u, v, m.q), w, wp, m.q);
       }
     }
     step <<= 1;
   }
 #pragma unroll
-  for (int j = 0; j < L_; ++j) a[j] = mulmod(a[j], linv, m);
+  for (int j = 0; j < L_; ++j) a[j] = mulmod_shoup(a[j], linv, linvp, m.q);
 }
 
 }  // namespace pvw

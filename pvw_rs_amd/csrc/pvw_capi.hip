@@ -209,7 +209,7 @@ static void build_tables(pvw_ctx* c) {
 
 static int32_t upload_tables(pvw_ctx* c) {
   const size_t L = c->L, l = c->l;
-  const size_t bytes = L * sizeof(Mod) + 4 * L * l * 8 + L * 8;
+  const size_t bytes = L * sizeof(Mod) + 8 * L * l * 8 + 2 * L * 8;
   if (!c->d_tables) PVW_HIP(hipMalloc(&c->d_tables, bytes));
   char* p = (char*)c->d_tables;
   auto put = [&](const void* src, size_t n) -> const void* {
@@ -224,6 +224,19 @@ static int32_t upload_tables(pvw_ctx* c) {
   c->dt.ghat = (const u64*)put(c->ghat.data(), L * l * 8);
   c->dt.gpow = (const u64*)put(c->gpow.data(), L * l * 8);
   c->dt.linv = (const u64*)put(c->linv.data(), L * 8);
+  // Shoup companions floor(x * 2^64 / q)
+  auto shoup = [&](const std::vector<u64>& src, size_t per_limb) {
+    std::vector<u64> out(src.size());
+    for (size_t i = 0; i < src.size(); ++i) out[i] = shoup_precompute(src[i], c->moduli[i / per_limb]);
+    return out;
+  };
+  std::vector<u64> twp = shoup(c->tw, l), itwp = shoup(c->itw, l), ghatp = shoup(c->ghat, l),
+                   gpowp = shoup(c->gpow, l), linvp = shoup(c->linv, 1);
+  c->dt.twp = (const u64*)put(twp.data(), L * l * 8);
+  c->dt.itwp = (const u64*)put(itwp.data(), L * l * 8);
+  c->dt.ghatp = (const u64*)put(ghatp.data(), L * l * 8);
+  c->dt.gpowp = (const u64*)put(gpowp.data(), L * l * 8);
+  c->dt.linvp = (const u64*)put(linvp.data(), L * 8);
   PVW_HIP(hipDeviceSynchronize());
   return PVW_OK;
 }
@@ -935,30 +948,24 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
                                u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
   const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
   const size_t P = c->poly();
-  const i64 *d_r, *d_e1, *d_e2;
-  if (rnd->mode == PVW_RND_SEED) {
-    SampleJob jr{}, j1{}, j2{};
-    PVW_TRY(cbd_job(c->variance, jr));                                              // encryption.rs:135-142
-    jr.domain = DOM_R; jr.index0 = 0; jr.count = k; jr.out_poly0 = 0;
-    j1.kind = SAMPLE_UNIFORM; j1.domain = DOM_E1; j1.index0 = c->c1_lo; j1.count = rA; j1.out_poly0 = k; j1.bound = c->b1;       // :161-167
-    j2.kind = SAMPLE_UNIFORM; j2.domain = DOM_E2; j2.index0 = c->party_lo; j2.count = rB; j2.out_poly0 = 2 * k; j2.bound = c->b2; // :196
-    ProfScope ps(c, "sample", s);
-    PVW_HIP(launch_sample(w->small, make_key(rnd->seed), l, jr, j1, j2, s));
-    d_r = w->small;
-    d_e1 = w->small + (size_t)k * l;
-    d_e2 = w->small + (size_t)2 * k * l;
-  } else {
-    d_r = rnd->r;
-    d_e1 = rnd->e1 + (size_t)c->c1_lo * l;
-    d_e2 = rnd->e2 + (size_t)c->party_lo * l;
+  PrologueJob jr{}, j1{}, j2{};
+  PVW_TRY(cbd_job(c->variance, jr.sj));                                             // encryption.rs:135-142
+  jr.sj.domain = DOM_R; jr.sj.index0 = 0; jr.sj.count = k;
+  j1.sj.kind = SAMPLE_UNIFORM; j1.sj.domain = DOM_E1; j1.sj.index0 = c->c1_lo; j1.sj.count = rA; j1.sj.bound = c->b1;     // :161-167
+  j2.sj.kind = SAMPLE_UNIFORM; j2.sj.domain = DOM_E2; j2.sj.index0 = c->party_lo; j2.sj.count = rB; j2.sj.bound = c->b2;  // :196
+  if (rnd->mode == PVW_RND_EXPLICIT) {
+    jr.explicit_coeffs = rnd->r;
+    j1.explicit_coeffs = rnd->e1 + (size_t)c->c1_lo * l;
+    j2.explicit_coeffs = rnd->e2 + (size_t)c->party_lo * l;
   }
+  // r -> r-hat [L][k][l] (:147-154); NTT(e1) -> c1 rows; NTT(e2) + scalar*g-hat -> c2 rows
+  // (the MAC kernel adds its sums onto them)
+  jr.out = w->rhat; jr.stride_poly = l; jr.stride_limb = (size_t)k * l;
+  j1.out = d_c1; j1.stride_poly = P; j1.stride_limb = l;
+  j2.out = d_c2; j2.stride_poly = P; j2.stride_limb = l; j2.scalars = d_scalars + c->party_lo;
   {
-    ProfScope ps(c, "prep", s);
-    // r -> r-hat [L][k][l]   (encryption.rs:147-154)
-    PVW_HIP(launch_prep(d_r, nullptr, w->rhat, l, (size_t)k * l, k, true, c->dt, L, l, s));
-    // NTT(e1) -> c1 rows; NTT(e2) + scalar*g-hat -> c2 rows (the MAC kernel adds onto them)
-    PVW_HIP(launch_prep(d_e1, nullptr, d_c1, P, l, rA, true, c->dt, L, l, s));
-    PVW_HIP(launch_prep(d_e2, d_scalars + c->party_lo, d_c2, P, l, rB, true, c->dt, L, l, s));
+    ProfScope ps(c, "prologue", s);
+    PVW_HIP(launch_prologue(make_key(rnd->seed), jr, j1, j2, c->dt, L, l, s));
   }
   {
     ProfScope ps(c, "mac_rows", s);

@@ -17,6 +17,12 @@ struct DevTables {
   const u64* linv;   // [L]     l^-1 mod q
   const u64* ghat;   // [L][l]  NTT(gadget)              (parameters.rs:288-308)
   const u64* gpow;   // [L][l]  gadget residues D^j mod q (power basis)
+  // Shoup companions floor(x * 2^64 / q) of the five tables above
+  const u64* twp;
+  const u64* itwp;
+  const u64* linvp;
+  const u64* ghatp;
+  const u64* gpowp;
 };
 
 enum { SAMPLE_CBD = 0, SAMPLE_UNIFORM = 1 };
@@ -55,6 +61,18 @@ hipError_t launch_untile(const u64* M, u64* dst, u32 rows, u32 row0_tiled, u32 k
 hipError_t launch_fill_uniform_tiled(u64* M, const ChaChaKey& key, u32 domain, u32 rows,
                                      u32 row0_tiled, u32 grow0, u32 k, u32 L, u32 ell,
                                      const DevTables& t, hipStream_t s);
+// one family of small polynomials of the encrypt prologue: sampled (explicit_coeffs == NULL) or
+// supplied, reduced + transformed into out[p*stride_poly + limb*stride_limb + slot],
+// optionally with scalars[p] * g-hat added (encode_scalar, parameters.rs:346-367)
+struct PrologueJob {
+  SampleJob sj;
+  const i64* explicit_coeffs;
+  const u64* scalars;
+  u64* out;
+  size_t stride_poly, stride_limb;
+};
+hipError_t launch_prologue(const ChaChaKey& key, const PrologueJob& j0, const PrologueJob& j1,
+                           const PrologueJob& j2, const DevTables& t, u32 L, u32 ell, hipStream_t s);
 hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJob& j0,
                          const SampleJob& j1, const SampleJob& j2, hipStream_t s);
 hipError_t launch_gaussian(i64* out, const ChaChaKey& key, u32 index0, u32 count, u64 bound,

@@ -155,13 +155,14 @@ __global__ __launch_bounds__(64) void prep_kernel(const i64* __restrict__ coeffs
   u64 a[ELL];
 #pragma unroll
   for (int s = 0; s < ELL; ++s) a[s] = signed_residue(coeffs[(size_t)p * ELL + s], m);
-  if (do_ntt) ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, m);
+  if (do_ntt) ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, m);
   if (scalars) {
     // `scalars[i] as i64` wrap (encryption.rs:195), then scalar * g  (parameters.rs:346-367)
     const u64 mr = signed_residue((i64)scalars[p], m);
     const u64* g = (do_ntt ? t.ghat : t.gpow) + (size_t)limb * ELL;
+    const u64* gp = (do_ntt ? t.ghatp : t.gpowp) + (size_t)limb * ELL;
 #pragma unroll
-    for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod(mr, g[s], m), m.q);
+    for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod_shoup(mr, g[s], gp[s], m.q), m.q);
   }
   u64* o = out + (size_t)p * stride_poly + (size_t)limb * stride_limb;
 #pragma unroll
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(64) void ntt_kernel(u64* __restrict__ polys, u32 co
     a[s] = v.x;
     a[s + 1] = v.y;
   }
-  if (inverse) ntt_inverse<ELL>(a, t.itw + (size_t)limb * ELL, t.linv[limb], m);
-  else ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, m);
+  if (inverse) ntt_inverse<ELL>(a, t.itw + (size_t)limb * ELL, t.itwp + (size_t)limb * ELL, t.linv[limb], t.linvp[limb], m);
+  else ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, m);
 #pragma unroll
   for (int s = 0; s < ELL; s += 2)
     *reinterpret_cast<v2u64*>(p + s) = (v2u64){a[s], a[s + 1]};
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const u64* __restrict__ src, 
     a[s] = v.x;
     a[s + 1] = v.y;
   }
-  if (ntt_first) ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.mods[limb]);
+  if (ntt_first) ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, t.mods[limb]);
   const u32 trow = row0_tiled + row;
   u64* o = M + (((size_t)(trow / R) * L + limb) * k + j) * 128 + (trow % R) * ELL;
 #pragma unroll
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void untile_kernel(const u64* __restrict__ M, 
     a[s] = v.x;
     a[s + 1] = v.y;
   }
-  if (intt_after) ntt_inverse<ELL>(a, t.itw + (size_t)limb * ELL, t.linv[limb], t.mods[limb]);
+  if (intt_after) ntt_inverse<ELL>(a, t.itw + (size_t)limb * ELL, t.itwp + (size_t)limb * ELL, t.linv[limb], t.linvp[limb], t.mods[limb]);
   u64* o = dst + tid * ELL;
 #pragma unroll
   for (int s = 0; s < ELL; s += 2)
@@ -298,6 +299,60 @@ __global__ __launch_bounds__(64) void sample_kernel(i64* __restrict__ out, ChaCh
   auto emit = [o](u32 s, i64 v) { o[s] = v; };
   if (job.kind == SAMPLE_CBD) sample_cbd_poly(g, l, job.cbd_half != 0, job.cbd_v, emit);
   else sample_uniform_poly(g, l, job.bound, emit);
+}
+
+// ------------------------------------------------------------------------------------
+// prologue: everything encrypt needs before the streamed MAC, in ONE launch
+// (encryption.rs:135-154 r, :161-167 e1, :195-196 encode + e2): each block takes PB
+// polynomials, samples (or copies) their small coefficients into LDS with one thread per
+// polynomial, then one thread per (polynomial, limb) reduces, transforms and stores.
+// ------------------------------------------------------------------------------------
+template <int ELL>
+__global__ __launch_bounds__(256) void prologue_kernel(ChaChaKey key, PrologueJob j0, PrologueJob j1,
+                                                        PrologueJob j2, u32 L, u32 PB, DevTables t) {
+  __shared__ i64 sc[64 * ELL];
+  const u32 total = j0.sj.count + j1.sj.count + j2.sj.count;
+  const u32 gp0 = blockIdx.x * PB;
+  const u32 tid = threadIdx.x;
+  if (tid < PB && gp0 + tid < total) {
+    const u32 gp = gp0 + tid;
+    const PrologueJob& job = gp < j0.sj.count ? j0 : (gp < j0.sj.count + j1.sj.count ? j1 : j2);
+    const u32 local = gp < j0.sj.count ? gp : (gp < j0.sj.count + j1.sj.count ? gp - j0.sj.count
+                                                                             : gp - j0.sj.count - j1.sj.count);
+    i64* o = sc + tid * ELL;
+    if (job.explicit_coeffs) {
+#pragma unroll
+      for (int s = 0; s < ELL; ++s) o[s] = job.explicit_coeffs[(size_t)local * ELL + s];
+    } else {
+      ChaChaRng g;
+      g.init(key, job.sj.domain, job.sj.index0 + local);
+      auto emit = [o](u32 s, i64 v) { o[s] = v; };
+      if (job.sj.kind == SAMPLE_CBD) sample_cbd_poly(g, ELL, job.sj.cbd_half != 0, job.sj.cbd_v, emit);
+      else sample_uniform_poly(g, ELL, job.sj.bound, emit);
+    }
+  }
+  __syncthreads();
+  const u32 p = tid / L, limb = tid % L;
+  if (p >= PB || gp0 + p >= total) return;
+  const u32 gp = gp0 + p;
+  const PrologueJob& job = gp < j0.sj.count ? j0 : (gp < j0.sj.count + j1.sj.count ? j1 : j2);
+  const u32 local = gp < j0.sj.count ? gp : (gp < j0.sj.count + j1.sj.count ? gp - j0.sj.count
+                                                                           : gp - j0.sj.count - j1.sj.count);
+  const Mod m = t.mods[limb];
+  u64 a[ELL];
+#pragma unroll
+  for (int s = 0; s < ELL; ++s) a[s] = signed_residue(sc[p * ELL + s], m);
+  ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, m);
+  if (job.scalars) {
+    const u64 mr = signed_residue((i64)job.scalars[local], m);   // `as i64` wrap, encryption.rs:195
+    const u64* g = t.ghat + (size_t)limb * ELL;
+    const u64* gp = t.ghatp + (size_t)limb * ELL;
+#pragma unroll
+    for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod_shoup(mr, g[s], gp[s], m.q), m.q);
+  }
+  u64* o = job.out + (size_t)local * job.stride_poly + (size_t)limb * job.stride_limb;
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2) *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
 }
 
 // truncated discrete Gaussian (src/sampling/normal.rs:136-190): one thread per sample.
@@ -484,6 +539,18 @@ hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJo
   const u32 threads = j0.count + j1.count + j2.count;
   if (threads == 0) return hipSuccess;
   sample_kernel<<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(out, key, ell, j0, j1, j2);
+  return hipGetLastError();
+}
+
+hipError_t launch_prologue(const ChaChaKey& key, const PrologueJob& j0, const PrologueJob& j1,
+                           const PrologueJob& j2, const DevTables& t, u32 L, u32 ell, hipStream_t s) {
+  const u32 total = j0.sj.count + j1.sj.count + j2.sj.count;
+  if (total == 0) return hipSuccess;
+  if (L > 256) return hipErrorInvalidValue;
+  u32 PB = 256 / L;
+  if (PB > 64) PB = 64;
+  const u32 blocks = (total + PB - 1) / PB;
+  PVW_DISPATCH_ELL(ell, prologue_kernel<E><<<dim3(blocks), dim3(256), 0, s>>>(key, j0, j1, j2, L, PB, t));
   return hipGetLastError();
 }
 
