@@ -94,31 +94,24 @@ def main():
     n_per, k, l, L, desc = CONFIGS[args.config or "c3"]
     n_total = n_per * world
     moduli = M.bench_moduli(L)
-    lo, hi = rank * n_per, (rank + 1) * n_per
-    clo, chi = k * rank // world, k * (rank + 1) // world
-    params = (P.PvwParametersBuilder().set_parties(n_total).set_dimension(k).set_l(l).set_moduli(moduli)
-              .set_secret_variance(0.5).set_error_bounds_u32(100, 200).set_device(local_rank)
-              .set_shard(lo, hi, clo, chi).build())
+    from pvw_rs_amd import dist as D
+    lo, hi, clo, chi = D.shard_ranges(n_total, k, world, rank)
+    params = D.sharded_builder(n_total, k, l, moduli, world, rank, device=local_rank) \
+        .set_secret_variance(0.5).set_error_bounds_u32(100, 200).build()
     h = params._h
     lib = _ffi.lib()
 
     # ---- residency: A-hat (generated on rank 0, broadcast ONCE over RCCL/xGMI), B-hat shard ----
     if world > 1:
-        import torch.distributed as dist
-        a_dev = torch.empty((k, k, L, l), dtype=torch.int64, device=dev)
+        a_host = None
         if rank == 0:
             p0 = (P.PvwParametersBuilder().set_parties(n_total).set_dimension(k).set_l(l).set_moduli(moduli)
                   .set_device(local_rank).build())
             a_host = P.PvwCrs.new_deterministic(p0, SEED_A).matrix(P.REPR_NTT)
-            a_dev.copy_(torch.from_numpy(a_host.view(np.int64)))
             del p0
-        dist.broadcast(a_dev, src=0)
-        torch.cuda.synchronize()
-        P.api._check(lib.pvw_load_crs_device(h, C.c_void_p(a_dev.data_ptr()), P.REPR_NTT,
-                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        torch.cuda.synchronize()
-        del a_dev
-        crs = P.PvwCrs(params)
+        a_dev = D.broadcast_crs(a_host, (k, k, L, l), src=0, device=dev)
+        crs = D.load_broadcast_crs(params, a_dev)
+        del a_dev, a_host
     else:
         crs = P.PvwCrs.new_deterministic(params, SEED_A)
     gpk = P.GlobalPublicKey.new(crs)

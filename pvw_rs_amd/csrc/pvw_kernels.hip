@@ -18,6 +18,8 @@
 //   the rest      O(n + k) polynomials, launch-latency sized
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pvw_arith.h"
 #include "pvw_chacha.h"
 #include "pvw_kernels.h"
@@ -31,14 +33,13 @@ typedef u64 v2u64 __attribute__((ext_vector_type(2)));  // one 16-byte lane acce
 // grid = row_blocks * L workgroups of 256 threads; the 4 waves split the j range, each
 // streaming a contiguous run of 1-KiB tiles; r-hat slices are staged in wave-private LDS.
 // ------------------------------------------------------------------------------------
-template <int ELL>
+template <int ELL, int U, bool NT, bool DBUF>
 __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection sb,
                                                         const u64* __restrict__ rhat,
                                                         const Mod* __restrict__ mods, u32 k, u32 L) {
   constexpr int HALF = ELL / 2;   // 16-byte slot pairs per polynomial limb
   constexpr int R = 128 / ELL;    // rows per tile
   constexpr int JC = ELL <= 16 ? 64 : (ELL == 32 ? 32 : 16);  // j per staged r-hat chunk (LDS <= 32 KiB)
-  constexpr int U = 8;            // tiles in flight per wave per buffer
   __shared__ v2u64 lds[4 * JC * HALF];
 
   // section a = A-hat rows (c1), section b = B-hat rows (c2): one launch covers both
@@ -74,30 +75,48 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
 
     const v2u64* mp = Mp + (size_t)jc * 64;
     u32 jj = 0;
-    if (cnt >= U) {
-      v2u64 x[U], xn[U];
+    auto ld = [&](size_t tile) -> v2u64 {
+      if constexpr (NT) return __builtin_nontemporal_load(mp + tile * 64);
+      else return mp[tile * 64];
+    };
+    if constexpr (DBUF) {
+      // two register buffers: the next U tiles are in flight while the current U are consumed
+      if (cnt >= U) {
+        v2u64 x[U], xn[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(mp + (size_t)u * 64);
-      for (; jj + 2 * U <= cnt; jj += U) {
+        for (int u = 0; u < U; ++u) x[u] = ld(u);
+        for (; jj + 2 * U <= cnt; jj += U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          xn[u] = __builtin_nontemporal_load(mp + (size_t)(jj + U + u) * 64);
+          for (int u = 0; u < U; ++u) xn[u] = ld(jj + U + u);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            v2u64 y = lw[(jj + u) * HALF + sp];
+            acc_mac_dev(a0, x[u].x, y.x);
+            acc_mac_dev(a1, x[u].y, y.y);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) x[u] = xn[u];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           v2u64 y = lw[(jj + u) * HALF + sp];
           acc_mac_dev(a0, x[u].x, y.x);
           acc_mac_dev(a1, x[u].y, y.y);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = xn[u];
+        jj += U;
       }
+    } else {
+      for (; jj + U <= cnt; jj += U) {
+        v2u64 x[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        v2u64 y = lw[(jj + u) * HALF + sp];
-        acc_mac_dev(a0, x[u].x, y.x);
-        acc_mac_dev(a1, x[u].y, y.y);
+        for (int u = 0; u < U; ++u) x[u] = ld(jj + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v2u64 y = lw[(jj + u) * HALF + sp];
+          acc_mac_dev(a0, x[u].x, y.x);
+          acc_mac_dev(a1, x[u].y, y.y);
+        }
       }
-      jj += U;
     }
     for (; jj < cnt; ++jj) {
       v2u64 xv = mp[(size_t)jj * 64];
@@ -401,6 +420,7 @@ __global__ __launch_bounds__(64) void gaussian_kernel(i64* __restrict__ out, Cha
 // on the ciphertext layout as it arrives, [d][j][L][l].  One workgroup per dealer; thread
 // (g, e) owns slot pair e of the polynomial and the j = g, g+c, g+2c, ... terms.
 // ------------------------------------------------------------------------------------
+template <int U, bool DBUF>
 __global__ __launch_bounds__(1024) void decrypt_mac_kernel(const u64* __restrict__ c1s,
                                                             const u64* __restrict__ shat,
                                                             const u64* __restrict__ c2col,
@@ -422,17 +442,50 @@ __global__ __launch_bounds__(1024) void decrypt_mac_kernel(const u64* __restrict
   acc_zero(a1);
   if (active) {
     u32 j = g;
-    for (; j + 3 * c < k; j += 4 * c) {
-      v2u64 x0 = __builtin_nontemporal_load(cp + (size_t)j * pairs);
-      v2u64 x1 = __builtin_nontemporal_load(cp + (size_t)(j + c) * pairs);
-      v2u64 x2 = __builtin_nontemporal_load(cp + (size_t)(j + 2 * c) * pairs);
-      v2u64 x3 = __builtin_nontemporal_load(cp + (size_t)(j + 3 * c) * pairs);
-      v2u64 y0 = sp[(size_t)j * pairs], y1 = sp[(size_t)(j + c) * pairs];
-      v2u64 y2 = sp[(size_t)(j + 2 * c) * pairs], y3 = sp[(size_t)(j + 3 * c) * pairs];
-      acc_mac_dev(a0, x0.x, y0.x); acc_mac_dev(a1, x0.y, y0.y);
-      acc_mac_dev(a0, x1.x, y1.x); acc_mac_dev(a1, x1.y, y1.y);
-      acc_mac_dev(a0, x2.x, y2.x); acc_mac_dev(a1, x2.y, y2.y);
-      acc_mac_dev(a0, x3.x, y3.x); acc_mac_dev(a1, x3.y, y3.y);
+    const size_t stride = (size_t)c * pairs;       // one step of this thread through j
+    if constexpr (DBUF) {
+      if (j + (U - 1) * c < k) {
+        v2u64 x[U], y[U], xn[U], yn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          x[u] = __builtin_nontemporal_load(cp + (size_t)j * pairs + u * stride);
+          y[u] = sp[(size_t)j * pairs + u * stride];
+        }
+        for (; j + (2 * U - 1) * c < k; j += U * c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            xn[u] = __builtin_nontemporal_load(cp + (size_t)(j + U * c) * pairs + u * stride);
+            yn[u] = sp[(size_t)(j + U * c) * pairs + u * stride];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            acc_mac_dev(a0, x[u].x, y[u].x);
+            acc_mac_dev(a1, x[u].y, y[u].y);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) { x[u] = xn[u]; y[u] = yn[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc_mac_dev(a0, x[u].x, y[u].x);
+          acc_mac_dev(a1, x[u].y, y[u].y);
+        }
+        j += U * c;
+      }
+    } else {
+      for (; j + (U - 1) * c < k; j += U * c) {
+        v2u64 x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          x[u] = __builtin_nontemporal_load(cp + (size_t)j * pairs + u * stride);
+          y[u] = sp[(size_t)j * pairs + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc_mac_dev(a0, x[u].x, y[u].x);
+          acc_mac_dev(a1, x[u].y, y[u].y);
+        }
+      }
     }
     for (; j < k; j += c) {
       v2u64 x0 = cp[(size_t)j * pairs];
@@ -462,6 +515,84 @@ __global__ __launch_bounds__(1024) void decrypt_mac_kernel(const u64* __restrict
   }
 }
 
+// decrypt_mac, dealer-grouped form: one workgroup serves DG dealers, so every s-hat pair fetched
+// (through L2) is used DG times and the vector-memory instruction count per streamed byte drops
+// from 2 to 1 + 1/DG.  Thread (g, e) as above; UJ j-steps are issued together.
+template <int DG, int UJ, int MAXT>
+__global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __restrict__ c1s,
+                                                                    const u64* __restrict__ shat,
+                                                                    const u64* __restrict__ c2col,
+                                                                    u64* __restrict__ noisy,
+                                                                    const Mod* __restrict__ mods, u32 k,
+                                                                    u32 ell, u32 pairs, u32 c, u32 dealers) {
+  extern __shared__ v2u64 dl[];
+  const u32 d0 = blockIdx.x * DG;
+  const u32 g = threadIdx.x / pairs, e = threadIdx.x % pairs;
+  const bool active = threadIdx.x < c * pairs;
+  const v2u64* sp = reinterpret_cast<const v2u64*>(shat) + e;
+  const v2u64* cp[DG];
+#pragma unroll
+  for (int dd = 0; dd < DG; ++dd) {
+    const u32 d = (d0 + dd) < dealers ? (d0 + dd) : (dealers - 1);   // clamp: tail group re-reads the last dealer
+    cp[dd] = reinterpret_cast<const v2u64*>(c1s) + (size_t)d * k * pairs + e;
+  }
+  Acc a0[DG], a1[DG];
+#pragma unroll
+  for (int dd = 0; dd < DG; ++dd) { acc_zero(a0[dd]); acc_zero(a1[dd]); }
+  if (active) {
+    u32 j = g;
+    for (; j + (UJ - 1) * c < k; j += UJ * c) {
+      v2u64 y[UJ], x[UJ][DG];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        y[u] = sp[(size_t)(j + u * c) * pairs];
+#pragma unroll
+        for (int dd = 0; dd < DG; ++dd) x[u][dd] = __builtin_nontemporal_load(cp[dd] + (size_t)(j + u * c) * pairs);
+      }
+#pragma unroll
+      for (int u = 0; u < UJ; ++u)
+#pragma unroll
+        for (int dd = 0; dd < DG; ++dd) {
+          acc_mac_dev(a0[dd], x[u][dd].x, y[u].x);
+          acc_mac_dev(a1[dd], x[u][dd].y, y[u].y);
+        }
+    }
+    for (; j < k; j += c) {
+      v2u64 y0 = sp[(size_t)j * pairs];
+#pragma unroll
+      for (int dd = 0; dd < DG; ++dd) {
+        v2u64 x0 = cp[dd][(size_t)j * pairs];
+        acc_mac_dev(a0[dd], x0.x, y0.x);
+        acc_mac_dev(a1[dd], x0.y, y0.y);
+      }
+    }
+  }
+  const u32 limb = active ? (2 * e) / ell : 0;
+  const Mod m = mods[limb];
+#pragma unroll
+  for (int dd = 0; dd < DG; ++dd) {
+    v2u64 part;
+    part.x = acc_reduce(a0[dd], m);
+    part.y = acc_reduce(a1[dd], m);
+    __syncthreads();
+    if (active) dl[threadIdx.x] = part;
+    __syncthreads();
+    if (active && g == 0 && d0 + dd < dealers) {
+      v2u64 sres = part;
+      for (u32 w = 1; w < c; ++w) {
+        v2u64 t = dl[w * pairs + e];
+        sres.x = addmod(sres.x, t.x, m.q);
+        sres.y = addmod(sres.y, t.y, m.q);
+      }
+      const size_t o = (size_t)(d0 + dd) * pairs + e;
+      v2u64 c2 = reinterpret_cast<const v2u64*>(c2col)[o];
+      sres.x = submod(sres.x, c2.x, m.q);
+      sres.y = submod(sres.y, c2.y, m.q);
+      reinterpret_cast<v2u64*>(noisy)[o] = sres;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
@@ -474,6 +605,33 @@ __global__ __launch_bounds__(1024) void decrypt_mac_kernel(const u64* __restrict
     default: return hipErrorInvalidValue;                \
   }
 
+// PVW_MAC_VARIANT (debug/tuning): selects the streaming schedule of mac_rows for l = 8 / 16
+//   0 (default) U=8 double-buffered nt | 1 same, default cache policy | 2 U=4 dbuf nt | 3 U=16 dbuf nt
+//   4 U=16 single buffer nt | 5 U=8 single buffer nt | 6 U=16 single buffer, default policy
+static int mac_variant() {
+  static int v = [] {
+    const char* e = getenv("PVW_MAC_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+template <int E>
+static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacSection& sa, const MacSection& sb,
+                               const u64* rhat, const Mod* mods, u32 k, u32 L) {
+  if constexpr (E <= 16) {
+    switch (variant) {
+      case 1: mac_rows_kernel<E, 8, false, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      case 2: mac_rows_kernel<E, 4, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      case 3: mac_rows_kernel<E, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      case 4: mac_rows_kernel<E, 16, true, false><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      case 5: mac_rows_kernel<E, 8, true, false><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      case 6: mac_rows_kernel<E, 16, false, false><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      default: break;
+    }
+  }
+  mac_rows_kernel<E, 8, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L);
+}
+
 hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat,
                            const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s) {
   const u32 R = 128 / ell;
@@ -482,7 +640,7 @@ hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* 
   sb.row_blocks = (sb.nrows + R - 1) / R;
   const u32 blocks = (sa.row_blocks + sb.row_blocks) * L;
   if (blocks == 0) return hipSuccess;
-  PVW_DISPATCH_ELL(ell, mac_rows_kernel<E><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L));
+  PVW_DISPATCH_ELL(ell, launch_mac_variant<E>(mac_variant(), dim3(blocks), s, sa, sb, rhat, t.mods, k, L));
   return hipGetLastError();
 }
 
@@ -580,10 +738,44 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
     threads = 1024;
   }
   const size_t lds = (size_t)threads * sizeof(v2u64);
+  // default: dealer-grouped DG=2, UJ=2 (best of the round-1 sweep: profiles/r01_variant_sweep.txt)
+  static int variant = [] { const char* e = getenv("PVW_DEC_VARIANT"); return e ? atoi(e) : 10; }();
+  if (variant >= 10 && ny == 1) {
+    // dealer-grouped kernels: variant 1x = DG 2, 2x = DG 4; x = 0: UJ 2, 1: UJ 4 (DG 2) / UJ 1 (DG 4)
+#define PVW_DEC_GROUPED(DGv, UJv)                                                                         \
+  do {                                                                                                    \
+    if (threads <= 512)                                                                                   \
+      decrypt_mac_grouped_kernel<DGv, UJv, 512><<<dim3((u32)((dealers + DGv - 1) / DGv)), dim3(threads), lds, s>>>( \
+          c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers);                                \
+    else                                                                                                  \
+      decrypt_mac_grouped_kernel<DGv, UJv, 1024><<<dim3((u32)((dealers + DGv - 1) / DGv)), dim3(threads), lds, s>>>( \
+          c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers);                                \
+  } while (0)
+    switch (variant) {
+      case 10: PVW_DEC_GROUPED(2, 2); break;
+      case 11: PVW_DEC_GROUPED(2, 4); break;
+      case 20: PVW_DEC_GROUPED(4, 2); break;
+      case 21: PVW_DEC_GROUPED(4, 1); break;
+      case 30: PVW_DEC_GROUPED(1, 8); break;
+      case 40: PVW_DEC_GROUPED(3, 2); break;
+      case 41: PVW_DEC_GROUPED(4, 2); break;
+      default: PVW_DEC_GROUPED(2, 2); break;
+    }
+#undef PVW_DEC_GROUPED
+    return hipGetLastError();
+  }
   for (size_t off = 0; off < dealers; off += 32768) {
     const u32 nd = (u32)((dealers - off) < 32768 ? (dealers - off) : 32768);
-    decrypt_mac_kernel<<<dim3(nd, ny), dim3(threads), lds, s>>>(c1s + off * (size_t)k * L * ell, shat, c2col + off * (size_t)L * ell,
-                       noisy + off * (size_t)L * ell, t.mods, k, ell, pairs, c, step);
+    const u64* c1p = c1s + off * (size_t)k * L * ell;
+    const u64* c2p = c2col + off * (size_t)L * ell;
+    u64* np = noisy + off * (size_t)L * ell;
+    switch (variant) {
+      case 1: decrypt_mac_kernel<4, false><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
+      case 2: decrypt_mac_kernel<8, false><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
+      case 3: decrypt_mac_kernel<8, true><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
+      case 4: decrypt_mac_kernel<2, true><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
+      default: decrypt_mac_kernel<4, true><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
+    }
   }
   return hipGetLastError();
 }
