@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS) + sorted(DECRYPT_CONFIGS))
+    ap.add_argument("--dealers", type=int, default=0,
+                    help="encrypt path only: > 0 batches this many dealers per step through pvw_encrypt_multi "
+                         "(encrypt_all_party_shares); value is then party-ciphertexts/s")
     ap.add_argument("--path", default="encrypt", choices=["encrypt", "decrypt"],
                     help="encrypt = the headline metric; decrypt = batched decrypt_party_value (BASELINE configs[4] shape)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -125,9 +128,21 @@ def main():
     C.memmove(rnd.seed, SEED_ENC, 32)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    Dm = args.dealers
+    if Dm > 0:
+        scalars_m = scalars.repeat(Dm, 1).contiguous()
+        c1m = torch.zeros((Dm, chi - clo, L, l), dtype=torch.int64, device=dev)
+        c2m = torch.zeros((Dm, n_per, L, l), dtype=torch.int64, device=dev)
+        seeds_m = np.concatenate([np.frombuffer(P.api._dealer_seed(SEED_ENC, d), dtype=np.uint8) for d in range(Dm)]).copy()
+
     def step():
-        rc = lib.pvw_encrypt_device(h, C.c_void_p(scalars.data_ptr()), n_total, C.byref(rnd),
-                                    C.c_void_p(c1.data_ptr()), C.c_void_p(c2.data_ptr()), P.REPR_NTT, stream)
+        if Dm > 0:
+            rc = lib.pvw_encrypt_multi_device(h, C.c_void_p(scalars_m.data_ptr()), Dm, n_total,
+                                              seeds_m.ctypes.data_as(C.c_void_p), C.c_void_p(c1m.data_ptr()),
+                                              C.c_void_p(c2m.data_ptr()), P.REPR_NTT, stream)
+        else:
+            rc = lib.pvw_encrypt_device(h, C.c_void_p(scalars.data_ptr()), n_total, C.byref(rnd),
+                                        C.c_void_p(c1.data_ptr()), C.c_void_p(c2.data_ptr()), P.REPR_NTT, stream)
         if rc != 0:
             raise RuntimeError(_ffi.last_error())
 
@@ -152,7 +167,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = n_total * args.steps / elapsed
+    value = n_total * max(Dm, 1) * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: HIP events around every mac_rows launch --------------
     params.set_profiling(True)
@@ -160,13 +175,14 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    kt = {name: params.kernel_time(name) for name in ("mac_rows", "prologue")}
+    kt = {name: params.kernel_time(name) for name in ("mac_rows", "mac_rows_multi", "prologue")}
     params.set_profiling(False)
-    mac_ms, mac_launches = kt["mac_rows"]
+    mac_ms, mac_launches = kt["mac_rows_multi"] if Dm > 0 else kt["mac_rows"]
     mac_avg_s = mac_ms / max(mac_launches, 1) * 1e-3
     rows_a = chi - clo
     # algorithmic bytes of one mac_rows launch: B-hat + A-hat reads, c2 + c1 writes, r-hat read
-    alg_bytes = 8 * L * l * (n_per * k + rows_a * k + n_per + rows_a + k)
+    nv = min(Dm, 4) if Dm > 0 else 1          # vectors sharing one pass over the matrix
+    alg_bytes = 8 * L * l * (n_per * k + rows_a * k + nv * (n_per + rows_a + k))
     achieved = alg_bytes / mac_avg_s / 1e9 if mac_avg_s > 0 else 0.0
 
     tr = measured_traffic(args.config or "c3", "mac_rows_kernel")
@@ -176,7 +192,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": desc, "parties_per_gpu": n_per, "parties_total": n_total, "k": k, "l": l,
-                   "rns_limbs": L, "q_bits": int(params.q_total().bit_length()), "randomness": "seed (ChaCha8), on device",
+                   "rns_limbs": L, "q_bits": int(params.q_total().bit_length()), "randomness": "seed (ChaCha8), on device", "dealers_per_step": max(Dm, 1),
                    "sharding": f"party-sharded x{world}, A-hat broadcast once, no data-path collective"},
         "roofline": {"bound": "hbm", "kernel": "mac_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
@@ -185,9 +201,14 @@ def main():
                      "launches_timed": mac_launches},
         "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},
     }
+    if Dm > 0:
+        out["metric"] = "party-ciphertexts/s for encrypt_all_party_shares (D dealers x n parties, 4 dealers per pass over B-hat)"
+        out["unit"] = "party-ciphertexts/s"
+        out["roofline"]["kernel"] = "mac_rows_multi_kernel"
+        out["roofline"]["modular_macs_per_s"] = L * l * (n_per * k + rows_a * k) * nv / mac_avg_s if mac_avg_s > 0 else 0.0
 
     # ---- CPU baseline: the C restatement (oracle/) on this box's host cores, rank 0, N=1 only ----
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and Dm == 0:
         import pvw_oracle as O
         n_cpu = min(n_per, 4096)
         orc = O.Oracle(moduli, l)

@@ -193,6 +193,20 @@ PVW_API int32_t pvw_encrypt_device(pvw_ctx* ctx, const uint64_t* d_scalars, size
                            const pvw_randomness_t* rnd, uint64_t* d_c1, uint64_t* d_c2,
                            uint32_t out_repr, void* stream);
 
+/* ---- multi-dealer encrypt: encrypt_all_party_shares (src/crypto/encryption.rs:253-286) ----
+ * Dealer d encrypts scalars[d][0..n) with its own randomness (seeds + 32*d, PVW_RND_SEED
+ * semantics).  Dealers are processed four at a time against ONE pass over A-hat / B-hat, so
+ * the public key is streamed D/4 times instead of D times.
+ * scalars [D][n]; c1_out [D][k][L][l]; c2_out [D][n][L][l].  scalars_per_dealer must be n (:264-274). */
+PVW_API int32_t pvw_encrypt_multi(pvw_ctx* ctx, const uint64_t* scalars, size_t num_dealers,
+                                  size_t scalars_per_dealer, const uint8_t* seeds /*[D][32]*/,
+                                  uint64_t* c1_out, uint64_t* c2_out, uint32_t out_repr);
+/* device-resident variant: d_scalars [D][n]; d_c1 [D][c1 rows held][L][l]; d_c2 [D][parties held][L][l];
+ * seeds stays a HOST pointer */
+PVW_API int32_t pvw_encrypt_multi_device(pvw_ctx* ctx, const uint64_t* d_scalars, size_t num_dealers,
+                                         size_t scalars_per_dealer, const uint8_t* seeds,
+                                         uint64_t* d_c1, uint64_t* d_c2, uint32_t out_repr, void* stream);
+
 /* ---- decrypt (src/crypto/decryption.rs:249-325) ------------------------------------
  * One secret key against D dealer ciphertexts (decrypt_party_shares :281-325):
  *   noisy_d = sum_j NTT(sk[j]) * c1s[d][j] - c2col[d]      (:257-274)

@@ -10,11 +10,11 @@ from ._ffi import (DOM_CRS, DOM_E1, DOM_E2, DOM_EKEY, DOM_GAUSS, DOM_PK, DOM_R, 
 from .api import (GlobalPublicKey, Party, PvwCiphertext, PvwCrs, PvwError, PvwParameters,
                   PvwParametersBuilder, SecretKey, decode_scalar_pvw, decrypt_party_shares,
                   decrypt_party_value, device_available, encrypt, encrypt_all_party_shares,
-                  encrypt_broadcast, encrypt_party_shares)
+                  encrypt_broadcast, encrypt_many, encrypt_party_shares)
 
 __all__ = [
     "PvwParametersBuilder", "PvwParameters", "PvwCrs", "SecretKey", "Party", "GlobalPublicKey",
     "PvwCiphertext", "PvwError", "encrypt", "encrypt_party_shares", "encrypt_all_party_shares",
-    "encrypt_broadcast", "decrypt_party_value", "decrypt_party_shares", "decode_scalar_pvw",
+    "encrypt_broadcast", "encrypt_many", "decrypt_party_value", "decrypt_party_shares", "decode_scalar_pvw",
     "device_available", "REPR_POWER", "REPR_NTT",
 ]

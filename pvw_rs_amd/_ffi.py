@@ -70,6 +70,8 @@ _SIGNATURES = {
     "pvw_sample_secret_keys": [_P, _P, C.c_uint32, C.c_uint32, _P],
     "pvw_encrypt": [_P, _P, C.c_size_t, C.POINTER(pvw_randomness_t), _P, _P, C.c_uint32],
     "pvw_encrypt_device": [_P, _P, C.c_size_t, C.POINTER(pvw_randomness_t), _P, _P, C.c_uint32, _P],
+    "pvw_encrypt_multi": [_P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, C.c_uint32],
+    "pvw_encrypt_multi_device": [_P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, C.c_uint32, _P],
     "pvw_decrypt_batch": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P],
     "pvw_decrypt_noisy_device": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P],
     "pvw_decode": [_P, _P, C.c_size_t, _P],

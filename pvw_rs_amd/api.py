@@ -542,15 +542,35 @@ def _dealer_seed(seed: bytes, dealer: int) -> bytes:
 
 
 def encrypt_all_party_shares(all_shares: Sequence[Sequence[int]], global_pk: GlobalPublicKey,
-                             seed: bytes, **kw) -> List[PvwCiphertext]:
-    """encryption.rs:253-286."""
-    n = global_pk.params.n
+                             seed: bytes, repr: int = REPR_NTT) -> List[PvwCiphertext]:
+    """encrypt_all_party_shares (encryption.rs:253-286): one batched device call; dealers share
+    passes over the public key four at a time (pvw_encrypt_multi).  Dealer d uses
+    `_dealer_seed(seed, d)`, so the result equals d separate `encrypt_party_shares` calls."""
+    p = global_pk.params
+    n = p.n
     if len(all_shares) != n:
         raise PvwError(1, f"Must provide shares for all {n} parties")
     for dealer_idx, dealer_shares in enumerate(all_shares):
         if len(dealer_shares) != n:
             raise PvwError(1, f"Dealer {dealer_idx} provided {len(dealer_shares)} shares but needs {n}")
-    return [encrypt_party_shares(sh, d, global_pk, _dealer_seed(seed, d), **kw) for d, sh in enumerate(all_shares)]
+    return encrypt_many(all_shares, global_pk, [_dealer_seed(seed, d) for d in range(len(all_shares))], repr)
+
+
+def encrypt_many(all_scalars: Sequence[Sequence[int]], global_pk: GlobalPublicKey, seeds: Sequence[bytes],
+                 repr: int = REPR_NTT) -> List[PvwCiphertext]:
+    """D independent encrypts (any D) batched through pvw_encrypt_multi."""
+    p = global_pk.params
+    D = len(all_scalars)
+    if len(seeds) != D:
+        raise PvwError(15, f"expected {D} seeds, got {len(seeds)}")
+    sc = np.array([[int(s) & 0xFFFFFFFFFFFFFFFF for s in row] for row in all_scalars], dtype=np.uint64)
+    if sc.ndim != 2:
+        raise PvwError(1, "ragged scalar rows")
+    sd = np.concatenate([_seed(s) for s in seeds]) if D else np.zeros(0, dtype=np.uint8)
+    c1 = np.zeros((D, p.k, p.L, p.l), dtype=np.uint64)
+    c2 = np.zeros((D, p.n, p.L, p.l), dtype=np.uint64)
+    _check(_ffi.lib().pvw_encrypt_multi(p._h, _ptr(sc), D, sc.shape[1] if D else 0, _ptr(sd), _ptr(c1), _ptr(c2), repr))
+    return [PvwCiphertext(c1[d], c2[d], p, repr) for d in range(D)]
 
 
 def encrypt_broadcast(scalar: int, global_pk: GlobalPublicKey, seed: bytes, **kw) -> PvwCiphertext:

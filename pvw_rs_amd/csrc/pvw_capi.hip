@@ -271,7 +271,7 @@ static int32_t ensure_device(pvw_ctx* c) {
 static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
   const size_t l = c->l, k = c->k, P = c->poly();
   PVW_HIP(hipMalloc((void**)&w->small, (2 * k + c->rowsB()) * l * sizeof(i64) + 16));
-  PVW_HIP(hipMalloc((void**)&w->rhat, k * P * 8));
+  PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
   return PVW_OK;
 }
 static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
@@ -943,29 +943,44 @@ static int32_t encrypt_checks(pvw_ctx* c, size_t num_scalars, const pvw_randomne
   return PVW_OK;
 }
 
-// all pointers are device pointers; explicit r/e1/e2 are GLOBAL arrays ([k][l], [k][l], [n][l])
-static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, const pvw_randomness_t* rnd,
-                               u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
-  const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
+// the three polynomial families of one encrypt (encryption.rs:135-154 r, :161-167 e1, :195-196
+// encode + e2) as prologue jobs [3*slot, 3*slot+3) seeded by key `slot` of the batch:
+// r -> r-hat [L][k][l]; NTT(e1) -> c1 rows; NTT(e2) + scalar*g-hat -> c2 rows (the MAC adds onto them)
+static int32_t fill_encrypt_jobs(pvw_ctx* c, PrologueBatch& pb, u32 slot, u32 /*unused*/, const pvw_randomness_t* rnd,
+                                 const u64* d_scalars, u64* rhat, u64* d_c1, u64* d_c2) {
+  const u32 k = c->k, l = c->l;
   const size_t P = c->poly();
-  PrologueJob jr{}, j1{}, j2{};
-  PVW_TRY(cbd_job(c->variance, jr.sj));                                             // encryption.rs:135-142
+  PrologueJob& jr = pb.job[3 * slot];
+  PrologueJob& j1 = pb.job[3 * slot + 1];
+  PrologueJob& j2 = pb.job[3 * slot + 2];
+  jr = PrologueJob{}; j1 = PrologueJob{}; j2 = PrologueJob{};
+  PVW_TRY(cbd_job(c->variance, jr.sj));
   jr.sj.domain = DOM_R; jr.sj.index0 = 0; jr.sj.count = k;
-  j1.sj.kind = SAMPLE_UNIFORM; j1.sj.domain = DOM_E1; j1.sj.index0 = c->c1_lo; j1.sj.count = rA; j1.sj.bound = c->b1;     // :161-167
-  j2.sj.kind = SAMPLE_UNIFORM; j2.sj.domain = DOM_E2; j2.sj.index0 = c->party_lo; j2.sj.count = rB; j2.sj.bound = c->b2;  // :196
+  j1.sj.kind = SAMPLE_UNIFORM; j1.sj.domain = DOM_E1; j1.sj.index0 = c->c1_lo; j1.sj.count = c->rowsA(); j1.sj.bound = c->b1;
+  j2.sj.kind = SAMPLE_UNIFORM; j2.sj.domain = DOM_E2; j2.sj.index0 = c->party_lo; j2.sj.count = c->rowsB(); j2.sj.bound = c->b2;
   if (rnd->mode == PVW_RND_EXPLICIT) {
     jr.explicit_coeffs = rnd->r;
     j1.explicit_coeffs = rnd->e1 + (size_t)c->c1_lo * l;
     j2.explicit_coeffs = rnd->e2 + (size_t)c->party_lo * l;
   }
-  // r -> r-hat [L][k][l] (:147-154); NTT(e1) -> c1 rows; NTT(e2) + scalar*g-hat -> c2 rows
-  // (the MAC kernel adds its sums onto them)
-  jr.out = w->rhat; jr.stride_poly = l; jr.stride_limb = (size_t)k * l;
+  jr.out = rhat; jr.stride_poly = l; jr.stride_limb = (size_t)k * l;
   j1.out = d_c1; j1.stride_poly = P; j1.stride_limb = l;
   j2.out = d_c2; j2.stride_poly = P; j2.stride_limb = l; j2.scalars = d_scalars + c->party_lo;
+  jr.key_idx = j1.key_idx = j2.key_idx = slot;
+  pb.key[slot] = make_key(rnd->seed);
+  return PVW_OK;
+}
+
+// all pointers are device pointers; explicit r/e1/e2 are GLOBAL arrays ([k][l], [k][l], [n][l])
+static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, const pvw_randomness_t* rnd,
+                               u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
+  const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
+  PrologueBatch pb{};
+  PVW_TRY(fill_encrypt_jobs(c, pb, 0, 0, rnd, d_scalars, w->rhat, d_c1, d_c2));
+  pb.njobs = 3;
   {
     ProfScope ps(c, "prologue", s);
-    PVW_HIP(launch_prologue(make_key(rnd->seed), jr, j1, j2, c->dt, L, l, s));
+    PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
   }
   {
     ProfScope ps(c, "mac_rows", s);
@@ -1024,6 +1039,111 @@ int32_t pvw_encrypt(pvw_ctx* c, const uint64_t* scalars, size_t num_scalars, con
        hipMemcpyAsync(c2_out + (size_t)c->party_lo * P, w->c2, (size_t)c->rowsB() * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
        hipStreamSynchronize(w->stream) != hipSuccess))
     rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  ws_release(c, w);
+  return rc;
+}
+
+// ------------------------------------------------------------------------ multi-dealer encrypt
+// encrypt_all_party_shares (encryption.rs:253-286): dealer d encrypts scalars[d][0..n) with its own
+// randomness (seed d).  Groups of 4 dealers share one pass over A-hat / B-hat (mac_rows_multi).
+// Device layout: d_scalars [D][n]; d_c1 [D][rowsA][L][l]; d_c2 [D][rowsB][L][l].
+static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, const uint8_t* seeds,
+                                     size_t D, u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
+  const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
+  const size_t P = c->poly();
+  for (size_t d0 = 0; d0 < D; d0 += 4) {
+    const u32 nv = (u32)((D - d0) < 4 ? (D - d0) : 4);
+    PrologueBatch pb{};
+    for (u32 v = 0; v < nv; ++v) {
+      pvw_randomness_t rnd{};
+      rnd.mode = PVW_RND_SEED;
+      memcpy(rnd.seed, seeds + (d0 + v) * 32, 32);
+      PVW_TRY(fill_encrypt_jobs(c, pb, v, 0, &rnd, d_scalars + (d0 + v) * c->n, w->rhat + (size_t)v * k * P,
+                                d_c1 + (d0 + v) * rA * P, d_c2 + (d0 + v) * rB * P));
+    }
+    pb.njobs = 3 * nv;
+    {
+      ProfScope ps(c, "prologue", s);
+      PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
+    }
+    {
+      ProfScope ps(c, "mac_rows_multi", s);
+      u64* c1g = d_c1 + d0 * rA * P;
+      u64* c2g = d_c2 + d0 * rB * P;
+      MacSection a{c->dA, c1g, c1g, rA, 0}, b{c->dB, c2g, c2g, rB, 0};
+      MultiVec mv{w->rhat, (size_t)k * P, (size_t)rA * P, (size_t)rB * P, nv};
+      PVW_HIP(launch_mac_rows_multi(a, b, mv, c->dt, k, L, l, s));
+    }
+  }
+  if (out_repr == PVW_REPR_POWER) {
+    ProfScope ps(c, "intt", s);
+    PVW_HIP(launch_ntt(d_c1, D * rA, true, c->dt, L, l, s));
+    PVW_HIP(launch_ntt(d_c2, D * rB, true, c->dt, L, l, s));
+  }
+  return PVW_OK;
+}
+
+static int32_t encrypt_multi_checks(pvw_ctx* c, size_t D, size_t per_dealer, uint32_t out_repr) {
+  PVW_TRY(check_repr(out_repr));
+  if (D == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "no dealers");
+  if (per_dealer != c->n) {                                                          // encryption.rs:264-274
+    char buf[96];
+    snprintf(buf, sizeof buf, "Dealer provided %zu shares but needs %u", per_dealer, c->n);
+    return fail(PVW_ERR_INVALID_PARAMETERS, buf);
+  }
+  if (c->num_keys < c->party_hi)
+    return fail(PVW_ERR_INVALID_PARAMETERS, "Global public key is not complete (missing party keys)");
+  if (!c->crs_loaded) return fail(PVW_ERR_CRS, "CRS not loaded");
+  int32_t ok = 0;
+  pvw_ctx_verify_correctness_condition(c, &ok);
+  if (!ok) return fail(PVW_ERR_INVALID_PARAMETERS, "Parameters do not satisfy correctness condition - decryption may fail");
+  return PVW_OK;
+}
+
+int32_t pvw_encrypt_multi_device(pvw_ctx* c, const uint64_t* d_scalars, size_t num_dealers, size_t scalars_per_dealer,
+                                 const uint8_t* seeds, uint64_t* d_c1, uint64_t* d_c2, uint32_t out_repr, void* stream) {
+  if (!c || !d_scalars || !seeds || (!d_c1 && c->rowsA()) || (!d_c2 && c->rowsB())) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(encrypt_multi_checks(c, num_dealers, scalars_per_dealer, out_repr));
+  PVW_TRY(ensure_device(c));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  Workspace* w;
+  PVW_TRY(ws_for_stream(c, s, &w));
+  return encrypt_multi_enqueue(c, w, d_scalars, seeds, num_dealers, d_c1, d_c2, out_repr, s);
+}
+
+int32_t pvw_encrypt_multi(pvw_ctx* c, const uint64_t* scalars, size_t num_dealers, size_t scalars_per_dealer,
+                          const uint8_t* seeds, uint64_t* c1_out, uint64_t* c2_out, uint32_t out_repr) {
+  if (!c || !scalars || !seeds || !c1_out || !c2_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(encrypt_multi_checks(c, num_dealers, scalars_per_dealer, out_repr));
+  PVW_TRY(ensure_device(c));
+  const size_t P = c->poly(), rA = c->rowsA(), rB = c->rowsB(), n = c->n;
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  // dealers per pass: bounded staging (<= ~512 MiB of ciphertext)
+  size_t per = ((size_t)512 << 20) / ((rA + rB) * P * 8 + n * 8);
+  if (per < 4) per = 4;
+  per &= ~(size_t)3;
+  if (per > num_dealers) per = num_dealers;
+  const size_t b_sc = (per * n * 8 + 255) & ~(size_t)255;
+  const size_t b_c1 = (per * rA * P * 8 + 255) & ~(size_t)255;
+  const size_t b_c2 = (per * rB * P * 8 + 255) & ~(size_t)255;
+  int32_t rc = ws_scratch(w, b_sc + b_c1 + b_c2);
+  for (size_t d0 = 0; rc == PVW_OK && d0 < num_dealers; d0 += per) {
+    const size_t cnt = (num_dealers - d0) < per ? (num_dealers - d0) : per;
+    char* base = (char*)w->scratch;
+    u64* d_sc = (u64*)base;
+    u64* d_c1 = (u64*)(base + b_sc);
+    u64* d_c2 = (u64*)(base + b_sc + b_c1);
+    if (hipMemcpyAsync(d_sc, scalars + d0 * n, cnt * n * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess) { rc = fail(PVW_ERR_INTERNAL, "H2D failed"); break; }
+    rc = encrypt_multi_enqueue(c, w, d_sc, seeds + d0 * 32, cnt, d_c1, d_c2, out_repr, w->stream);
+    for (size_t d = 0; rc == PVW_OK && d < cnt; ++d) {
+      // a sharded context writes its rows at their global positions inside each dealer's block
+      if (hipMemcpyAsync(c1_out + ((d0 + d) * c->k + c->c1_lo) * P, d_c1 + d * rA * P, rA * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+          hipMemcpyAsync(c2_out + ((d0 + d) * n + c->party_lo) * P, d_c2 + d * rB * P, rB * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess)
+        rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+    }
+    if (rc == PVW_OK && hipStreamSynchronize(w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");
+  }
   ws_release(c, w);
   return rc;
 }
@@ -1187,8 +1307,8 @@ int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, co
 // ------------------------------------------------------------------------ key generation
 // b_i = s_i * A + e_i: for every party the k-term inner products over A's COLUMNS, i.e. one
 // mac_rows pass over the transposed CRS per party (public_key.rs:111-147, crs.rs:138-171).
-// Round-1 implementation: the CRS is transposed once into a temporary tiled matrix and each
-// party's public key is one mac_rows launch with s-hat_i in the role of r-hat.
+// The CRS is transposed once per call into a temporary tiled matrix; groups of 4 parties then
+// share one pass over it (mac_rows_multi with s-hat_i in the role of r-hat).
 int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, const int64_t* ek, const uint8_t seed[32]) {
   if (!c || !sk) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   if (!ek && !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "either explicit key errors or a seed is required");
@@ -1206,8 +1326,8 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   // scratch: A in API layout [k][k][P] | A^T tiled | per-party: sk,ek small [2k][l], b row [k][P]
   const size_t b_api = ((size_t)k * k * P * 8 + 255) & ~(size_t)255;
   const size_t b_tt = (c->tiled_words(k) * 8 + 255) & ~(size_t)255;
-  const size_t b_small = ((size_t)2 * k * l * 8 + 255) & ~(size_t)255;
-  const size_t b_row = ((size_t)k * P * 8 + 255) & ~(size_t)255;
+  const size_t b_small = ((size_t)8 * k * l * 8 + 255) & ~(size_t)255;   // sk + ek of 4 parties
+  const size_t b_row = ((size_t)4 * k * P * 8 + 255) & ~(size_t)255;      // 4 rows of B
   int32_t rc = ws_scratch(w, 2 * b_api + b_tt + b_small + b_row);
   if (rc == PVW_OK) {
     char* base = (char*)w->scratch;
@@ -1224,23 +1344,34 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
     okk = okk && hipMemsetAsync(d_tt, 0, c->tiled_words(k) * 8, s) == hipSuccess;
     okk = okk && launch_tile(d_apiT, d_tt, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
     if (!okk) rc = fail(PVW_ERR_INTERNAL, "CRS transpose failed");
-    for (u32 p = a; rc == PVW_OK && p < b; ++p) {
-      const int64_t* skp = sk + (size_t)(p - lo) * k * l;
-      if (hipMemcpyAsync(d_small, skp, (size_t)k * l * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = fail(PVW_ERR_INTERNAL, "H2D failed"); break; }
-      if (ek) {
-        if (hipMemcpyAsync(d_small + (size_t)k * l, ek + (size_t)(p - lo) * k * l, (size_t)k * l * 8, hipMemcpyHostToDevice, s) != hipSuccess) { rc = fail(PVW_ERR_INTERNAL, "H2D failed"); break; }
-      } else {
-        SampleJob j{}, z{};
-        j.kind = SAMPLE_UNIFORM; j.domain = DOM_EKEY; j.index0 = p * k; j.count = k; j.out_poly0 = k; j.bound = c->b1;   // public_key.rs:128-132
-        if (launch_sample(d_small, make_key(seed), l, j, z, z, s) != hipSuccess) { rc = fail(PVW_ERR_INTERNAL, "sample launch failed"); break; }
+    // groups of 4 parties share one pass over the transposed CRS (mac_rows_multi)
+    for (u32 p0 = a; rc == PVW_OK && p0 < b; p0 += 4) {
+      const u32 nv = (b - p0) < 4 ? (b - p0) : 4;
+      const size_t words = (size_t)nv * k * l;
+      if (hipMemcpyAsync(d_small, sk + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+          (ek && hipMemcpyAsync(d_small + (size_t)4 * k * l, ek + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s) != hipSuccess)) {
+        rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+        break;
       }
+      PrologueBatch pb{};
+      if (seed) pb.key[0] = make_key(seed);
+      for (u32 v = 0; v < nv; ++v) {
+        PrologueJob& js = pb.job[2 * v];
+        PrologueJob& je = pb.job[2 * v + 1];
+        js.sj.count = k; js.explicit_coeffs = d_small + (size_t)v * k * l;                 // secret_key.rs:98-112
+        js.out = w->rhat + (size_t)v * k * P; js.stride_poly = l; js.stride_limb = (size_t)k * l;
+        je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = (p0 + v) * k; je.sj.count = k; je.sj.bound = c->b1;  // public_key.rs:128-132
+        if (ek) je.explicit_coeffs = d_small + (size_t)(4 + v) * k * l;
+        je.out = d_row + (size_t)v * k * P; je.stride_poly = P; je.stride_limb = l;
+      }
+      pb.njobs = 2 * nv;
       ProfScope ps(c, "keygen", s);
-      bool ok2 = launch_prep(d_small, nullptr, w->rhat, l, (size_t)k * l, k, true, c->dt, L, l, s) == hipSuccess;        // secret_key.rs:98-112
-      ok2 = ok2 && launch_prep(d_small + (size_t)k * l, nullptr, d_row, P, l, k, true, c->dt, L, l, s) == hipSuccess;     // NTT(e_i)
+      bool ok2 = launch_prologue(pb, c->dt, L, l, s) == hipSuccess;
       MacSection sa{d_tt, d_row, d_row, k, 0}, sb{nullptr, nullptr, nullptr, 0, 0};
-      ok2 = ok2 && launch_mac_rows(sa, sb, w->rhat, c->dt, k, L, l, s) == hipSuccess;                                       // crs.rs:152-168
-      // d_row is [k polys][P] = one row of B in API layout -> tile into B
-      ok2 = ok2 && launch_tile(d_row, c->dB, 1, p - c->party_lo, k, L, l, false, c->dt, s) == hipSuccess;
+      MultiVec mv{w->rhat, (size_t)k * P, (size_t)k * P, 0, nv};
+      ok2 = ok2 && launch_mac_rows_multi(sa, sb, mv, c->dt, k, L, l, s) == hipSuccess;                   // crs.rs:152-168
+      // d_row is [nv][k polys][P] = nv rows of B in API layout -> tile into B
+      ok2 = ok2 && launch_tile(d_row, c->dB, nv, p0 - c->party_lo, k, L, l, false, c->dt, s) == hipSuccess;
       if (!ok2) rc = fail(PVW_ERR_KEY_GENERATION, "keygen launch failed");
     }
     if (rc == PVW_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");

@@ -70,9 +70,29 @@ struct PrologueJob {
   const u64* scalars;
   u64* out;
   size_t stride_poly, stride_limb;
+  u32 key_idx;   // which key of the batch seeds this family
 };
-hipError_t launch_prologue(const ChaChaKey& key, const PrologueJob& j0, const PrologueJob& j1,
-                           const PrologueJob& j2, const DevTables& t, u32 L, u32 ell, hipStream_t s);
+#define PVW_MAX_PROLOGUE_JOBS 12
+#define PVW_MAX_PROLOGUE_KEYS 4
+// up to 4 encrypts' worth of polynomial families (r, e1, e2 each) in one launch
+struct PrologueBatch {
+  PrologueJob job[PVW_MAX_PROLOGUE_JOBS];
+  ChaChaKey key[PVW_MAX_PROLOGUE_KEYS];
+  u32 njobs;
+  u32 total;   // filled in by the launcher
+};
+hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s);
+
+// NV (<= 4) vectors sharing one pass over the tiled matrix (mac_rows_multi)
+struct MultiVec {
+  const u64* vhat;      // [nv][L][k][l]
+  size_t vstride;       // words between consecutive vectors
+  size_t out_stride_a;  // words between consecutive vectors' outputs / addends, section a
+  size_t out_stride_b;  // ... section b
+  u32 nv;
+};
+hipError_t launch_mac_rows_multi(const MacSection& a, const MacSection& b, const MultiVec& mv,
+                                 const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s);
 hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJob& j0,
                          const SampleJob& j1, const SampleJob& j2, hipStream_t s);
 hipError_t launch_gaussian(i64* out, const ChaChaKey& key, u32 index0, u32 count, u64 bound,

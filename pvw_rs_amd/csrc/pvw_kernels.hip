@@ -156,6 +156,116 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
 }
 
 // ------------------------------------------------------------------------------------
+// mac_rows_multi: NV vectors against one pass over the tiled matrix,
+//     out_v[row] = sum_j M[row][j] * vhat_v[j] + addend_v[row],   v < NV.
+// Every 16-byte tile element is loaded once and used for 2*NV modular MACs, so the kernel moves
+// from the HBM roofline (NV = 1: mac_rows) towards the integer-VALU roofline.  Serves
+//   * multi-dealer encrypt (encrypt_all_party_shares, encryption.rs:253-286): vectors = r-hat of
+//     NV dealers, matrix = [A-hat; B-hat];
+//   * batched key generation (public_key.rs:111-147 over crs.rs:138-171): vectors = s-hat of NV
+//     parties, matrix = transposed CRS.
+// ------------------------------------------------------------------------------------
+template <int ELL, int NV>
+__global__ __launch_bounds__(256) void mac_rows_multi_kernel(MacSection sa, MacSection sb, MultiVec mv,
+                                                              const Mod* __restrict__ mods, u32 k, u32 L) {
+  constexpr int HALF = ELL / 2;
+  constexpr int R = 128 / ELL;
+  constexpr int JC = ELL <= 8 ? 16 : (ELL == 16 ? 8 : (ELL == 32 ? 8 : 4));   // LDS = 4*NV*JC*HALF*16 B <= 32 KiB
+  constexpr int U = JC < 8 ? JC : 8;
+  __shared__ v2u64 lds[4 * NV * JC * HALF];
+
+  const u32 limb = blockIdx.x % L;
+  const u32 rbg = blockIdx.x / L;
+  const bool in_a = rbg < sa.row_blocks;
+  const u32 rb = in_a ? rbg : rbg - sa.row_blocks;
+  const u64* __restrict__ M = in_a ? sa.M : sb.M;
+  const u64* addend = in_a ? sa.addend : sb.addend;
+  u64* out = in_a ? sa.out : sb.out;
+  const u32 nrows = in_a ? sa.nrows : sb.nrows;
+  const size_t ostride = in_a ? mv.out_stride_a : mv.out_stride_b;
+
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 sp = lane % HALF, rho = lane / HALF;
+  const u32 kq = (k + 3) / 4;
+  const u32 j0 = wave * kq < k ? wave * kq : k;
+  const u32 j1 = (j0 + kq) < k ? (j0 + kq) : k;
+
+  const v2u64* Mp = reinterpret_cast<const v2u64*>(M + ((size_t)rb * L + limb) * (size_t)k * 128) + lane;
+  v2u64* lw = lds + wave * (NV * JC * HALF);
+
+  Acc a0[NV], a1[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { acc_zero(a0[v]); acc_zero(a1[v]); }
+
+  for (u32 jc = j0; jc < j1; jc += JC) {
+    const u32 cnt = (j1 - jc) < (u32)JC ? (j1 - jc) : (u32)JC;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const u32 vv = (u32)v < mv.nv ? (u32)v : mv.nv - 1;
+      const v2u64* rp = reinterpret_cast<const v2u64*>(mv.vhat + (size_t)vv * mv.vstride + (size_t)limb * k * ELL);
+      for (u32 idx = lane; idx < cnt * HALF; idx += 64) lw[v * (JC * HALF) + idx] = rp[(size_t)jc * HALF + idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const v2u64* mp = Mp + (size_t)jc * 64;
+    u32 jj = 0;
+    for (; jj + U <= cnt; jj += U) {
+      v2u64 x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = __builtin_nontemporal_load(mp + (size_t)(jj + u) * 64);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          v2u64 y = lw[v * (JC * HALF) + (jj + u) * HALF + sp];
+          acc_mac_dev(a0[v], x[u].x, y.x);
+          acc_mac_dev(a1[v], x[u].y, y.y);
+        }
+      }
+    }
+    for (; jj < cnt; ++jj) {
+      v2u64 xv = mp[(size_t)jj * 64];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        v2u64 y = lw[v * (JC * HALF) + jj * HALF + sp];
+        acc_mac_dev(a0[v], xv.x, y.x);
+        acc_mac_dev(a1[v], xv.y, y.y);
+      }
+    }
+  }
+
+  const Mod m = mods[limb];
+  const u32 row = rb * R + rho;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    v2u64 part;
+    part.x = acc_reduce(a0[v], m);
+    part.y = acc_reduce(a1[v], m);
+    __syncthreads();
+    lds[wave * 64 + lane] = part;
+    __syncthreads();
+    if (wave == 0 && row < nrows && (u32)v < mv.nv) {
+      v2u64 s = lds[lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        v2u64 t = lds[w * 64 + lane];
+        s.x = addmod(s.x, t.x, m.q);
+        s.y = addmod(s.y, t.y, m.q);
+      }
+      const size_t o = ((size_t)v * ostride + ((size_t)row * L + limb) * ELL) / 2 + sp;
+      if (addend) {
+        v2u64 e = reinterpret_cast<const v2u64*>(addend)[o];
+        s.x = addmod(s.x, e.x, m.q);
+        s.y = addmod(s.y, e.y, m.q);
+      }
+      reinterpret_cast<v2u64*>(out)[o] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // prep: small signed coefficients -> RNS -> l-point NTT (+ scalar * g-hat), one thread per
 // (polynomial, limb).  Serves r-hat, the e1/e2 addends, encode_scalar
 // (src/params/parameters.rs:346-367) and Poly::from_coefficients + NTT
@@ -327,24 +437,29 @@ __global__ __launch_bounds__(64) void sample_kernel(i64* __restrict__ out, ChaCh
 // polynomial, then one thread per (polynomial, limb) reduces, transforms and stores.
 // ------------------------------------------------------------------------------------
 template <int ELL>
-__global__ __launch_bounds__(256) void prologue_kernel(ChaChaKey key, PrologueJob j0, PrologueJob j1,
-                                                        PrologueJob j2, u32 L, u32 PB, DevTables t) {
+__global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u32 PB, DevTables t) {
   __shared__ i64 sc[64 * ELL];
-  const u32 total = j0.sj.count + j1.sj.count + j2.sj.count;
   const u32 gp0 = blockIdx.x * PB;
   const u32 tid = threadIdx.x;
-  if (tid < PB && gp0 + tid < total) {
-    const u32 gp = gp0 + tid;
-    const PrologueJob& job = gp < j0.sj.count ? j0 : (gp < j0.sj.count + j1.sj.count ? j1 : j2);
-    const u32 local = gp < j0.sj.count ? gp : (gp < j0.sj.count + j1.sj.count ? gp - j0.sj.count
-                                                                             : gp - j0.sj.count - j1.sj.count);
+  // locate (job, local polynomial) of global polynomial gp: jobs are laid end to end
+  auto locate = [&](u32 gp, u32& ji, u32& local) {
+    ji = 0;
+    local = gp;
+#pragma unroll
+    for (u32 x = 0; x + 1 < PVW_MAX_PROLOGUE_JOBS; ++x)
+      if (ji == x && x + 1 < b.njobs && local >= b.job[x].sj.count) { local -= b.job[x].sj.count; ji = x + 1; }
+  };
+  if (tid < PB && gp0 + tid < b.total) {
+    u32 ji, local;
+    locate(gp0 + tid, ji, local);
+    const PrologueJob& job = b.job[ji];
     i64* o = sc + tid * ELL;
     if (job.explicit_coeffs) {
 #pragma unroll
       for (int s = 0; s < ELL; ++s) o[s] = job.explicit_coeffs[(size_t)local * ELL + s];
     } else {
       ChaChaRng g;
-      g.init(key, job.sj.domain, job.sj.index0 + local);
+      g.init(b.key[job.key_idx], job.sj.domain, job.sj.index0 + local);
       auto emit = [o](u32 s, i64 v) { o[s] = v; };
       if (job.sj.kind == SAMPLE_CBD) sample_cbd_poly(g, ELL, job.sj.cbd_half != 0, job.sj.cbd_v, emit);
       else sample_uniform_poly(g, ELL, job.sj.bound, emit);
@@ -352,11 +467,10 @@ __global__ __launch_bounds__(256) void prologue_kernel(ChaChaKey key, PrologueJo
   }
   __syncthreads();
   const u32 p = tid / L, limb = tid % L;
-  if (p >= PB || gp0 + p >= total) return;
-  const u32 gp = gp0 + p;
-  const PrologueJob& job = gp < j0.sj.count ? j0 : (gp < j0.sj.count + j1.sj.count ? j1 : j2);
-  const u32 local = gp < j0.sj.count ? gp : (gp < j0.sj.count + j1.sj.count ? gp - j0.sj.count
-                                                                           : gp - j0.sj.count - j1.sj.count);
+  if (p >= PB || gp0 + p >= b.total) return;
+  u32 ji, local;
+  locate(gp0 + p, ji, local);
+  const PrologueJob& job = b.job[ji];
   const Mod m = t.mods[limb];
   u64 a[ELL];
 #pragma unroll
@@ -644,6 +758,23 @@ hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* 
   return hipGetLastError();
 }
 
+hipError_t launch_mac_rows_multi(const MacSection& a, const MacSection& b, const MultiVec& mv,
+                                 const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s) {
+  const u32 R = 128 / ell;
+  MacSection sa = a, sb = b;
+  sa.row_blocks = (sa.nrows + R - 1) / R;
+  sb.row_blocks = (sb.nrows + R - 1) / R;
+  const u32 blocks = (sa.row_blocks + sb.row_blocks) * L;
+  if (blocks == 0 || mv.nv == 0) return hipSuccess;
+  if (mv.nv > 4) return hipErrorInvalidValue;
+  if (mv.nv <= 2) {
+    PVW_DISPATCH_ELL(ell, mac_rows_multi_kernel<E, 2><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, mv, t.mods, k, L));
+  } else {
+    PVW_DISPATCH_ELL(ell, mac_rows_multi_kernel<E, 4><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, mv, t.mods, k, L));
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t stride_poly,
                        size_t stride_limb, u32 count, bool do_ntt, const DevTables& t, u32 L,
                        u32 ell, hipStream_t s) {
@@ -700,15 +831,17 @@ hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJo
   return hipGetLastError();
 }
 
-hipError_t launch_prologue(const ChaChaKey& key, const PrologueJob& j0, const PrologueJob& j1,
-                           const PrologueJob& j2, const DevTables& t, u32 L, u32 ell, hipStream_t s) {
-  const u32 total = j0.sj.count + j1.sj.count + j2.sj.count;
-  if (total == 0) return hipSuccess;
+hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s) {
+  PrologueBatch b = batch;
+  b.total = 0;
+  if (b.njobs > PVW_MAX_PROLOGUE_JOBS) return hipErrorInvalidValue;
+  for (u32 i = 0; i < b.njobs; ++i) b.total += b.job[i].sj.count;
+  if (b.total == 0) return hipSuccess;
   if (L > 256) return hipErrorInvalidValue;
   u32 PB = 256 / L;
   if (PB > 64) PB = 64;
-  const u32 blocks = (total + PB - 1) / PB;
-  PVW_DISPATCH_ELL(ell, prologue_kernel<E><<<dim3(blocks), dim3(256), 0, s>>>(key, j0, j1, j2, L, PB, t));
+  const u32 blocks = (b.total + PB - 1) / PB;
+  PVW_DISPATCH_ELL(ell, prologue_kernel<E><<<dim3(blocks), dim3(256), 0, s>>>(b, L, PB, t));
   return hipGetLastError();
 }
 

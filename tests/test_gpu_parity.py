@@ -299,6 +299,41 @@ def test_ragged_geometries_against_c_oracle(n, k, l, L):
     assert np.array_equal(noisy, orc.decrypt_noisy(sk, c1s, c2col))
 
 
+@pytest.mark.parametrize("D", [1, 4, 7])
+def test_multi_dealer_encrypt_equals_separate_encrypts(D):
+    # encrypt_all_party_shares (encryption.rs:253-286) batched four dealers per pass over B-hat
+    n, k, l, moduli = 13, 9, 8, M.bench_moduli(4)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    rows = [[(d * 100 + j) for j in range(1, n + 1)] for d in range(D)]
+    seeds = [P.api._dealer_seed(SEED, d) for d in range(D)]
+    for repr in (P.REPR_NTT, P.REPR_POWER):
+        many = P.encrypt_many(rows, gpk, seeds, repr)
+        assert len(many) == D
+        for d in range(D):
+            one = P.encrypt(rows[d], gpk, seeds[d], repr=repr)
+            assert np.array_equal(many[d].c1, one.c1) and np.array_equal(many[d].c2, one.c2)
+    with pytest.raises(P.PvwError):
+        P.encrypt_many([[1, 2, 3]], gpk, seeds[:1])
+
+
+def test_multi_dealer_encrypt_l16_and_sharded():
+    n, k, l, moduli = 10, 6, 16, TEST_MODULI
+    full = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(full, SEED))
+    gpk.fill_uniform(SEED)
+    rows = [[(d * 100 + j) for j in range(1, n + 1)] for d in range(n)]
+    cts = P.encrypt_all_party_shares(rows, gpk, SEED)
+    ps = build_params(n, k, l, moduli, shard=(3, 8, 2, 5))
+    g2 = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(ps, SEED))
+    g2.fill_uniform(SEED)
+    part = P.encrypt_all_party_shares(rows, g2, SEED)
+    for d in range(n):
+        assert np.array_equal(part[d].c1[2:5], cts[d].c1[2:5]) and np.array_equal(part[d].c2[3:8], cts[d].c2[3:8])
+        assert not part[d].c1[:2].any() and not part[d].c2[8:].any()
+
+
 def test_sharded_contexts_match_unsharded():
     # one process per GPU holds rows [party_lo, party_hi) of B and [c1_lo, c1_hi) of A
     n, k, l, moduli = 21, 12, 8, M.bench_moduli(3)
