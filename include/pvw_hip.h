@@ -220,8 +220,18 @@ PVW_API int32_t pvw_decrypt_batch(pvw_ctx* ctx, const int64_t* sk, const uint64_
 PVW_API int32_t pvw_decrypt_noisy_device(pvw_ctx* ctx, const int64_t* d_sk, const uint64_t* d_c1s,
                                  const uint64_t* d_c2col, size_t num_dealers, uint32_t in_repr,
                                  uint64_t* d_noisy, void* stream);
-/* decode_scalar_pvw_rns alone: noisy [D][L][l] power basis (host) -> out_u64 [D] */
-PVW_API int32_t pvw_decode(const pvw_ctx* ctx, const uint64_t* noisy, size_t count, uint64_t* out_u64);
+/* decode_scalar_pvw_rns alone, on the device: noisy [D][L][l] power basis (host) -> out_u64 [D] */
+PVW_API int32_t pvw_decode(pvw_ctx* ctx, const uint64_t* noisy, size_t count, uint64_t* out_u64);
+/* the same with host big integers on the host cores (no GPU needed): an independent
+ * implementation kept as a cross-check of the device algorithm and for GPU-less tooling */
+PVW_API int32_t pvw_decode_host(const pvw_ctx* ctx, const uint64_t* noisy, size_t count, uint64_t* out_u64);
+/* device pointers: d_noisy -> d_out [D].  pvw_decrypt_batch uses this, so only D x u64 leave the GPU. */
+PVW_API int32_t pvw_decode_device(pvw_ctx* ctx, const uint64_t* d_noisy, size_t count, uint64_t* d_out,
+                                  void* stream);
+/* SELF-TEST hook: runs the device decode algorithm (pvw_decode.h) on the host so it can be checked
+ * without a GPU.  No product path calls it. */
+PVW_API int32_t pvw_selftest_decode_fixed(const pvw_ctx* ctx, const uint64_t* noisy, size_t count,
+                                          uint64_t* out_u64);
 
 /* ---- ring primitives (fhe-math call sites) -----------------------
  * change_representation(Ntt / PowerBasis) on `count` polynomials, host buffers, in place */

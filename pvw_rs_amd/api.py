@@ -614,9 +614,25 @@ def decrypt_party_value(ciphertext: PvwCiphertext, secret_key: SecretKey, party_
     return _decrypt_batch(ciphertext.params, [ciphertext], secret_key, party_index)[0]
 
 
+def _selftest_decode_fixed(params: PvwParameters, noisy: np.ndarray) -> List[int]:
+    """Host run of the fixed-width decode the GPU executes (self-test hook, see pvw_hip.h)."""
+    a = _u64(noisy).reshape(-1, params.L, params.l)
+    out = np.zeros(len(a), dtype=np.uint64)
+    _check(_ffi.lib().pvw_selftest_decode_fixed(params._h, _ptr(a), len(a), _ptr(out)))
+    return [int(v) for v in out]
+
+
 def decode_scalar_pvw(params: PvwParameters, noisy: np.ndarray) -> List[int]:
-    """decode_scalar_pvw_rns (decryption.rs:10-58) on power-basis noisy polynomials [D][L][l]."""
+    """decode_scalar_pvw_rns (decryption.rs:10-58) on power-basis noisy polynomials [D][L][l], on the device."""
     a = _u64(noisy).reshape(-1, params.L, params.l)
     out = np.zeros(len(a), dtype=np.uint64)
     _check(_ffi.lib().pvw_decode(params._h, _ptr(a), len(a), _ptr(out)))
+    return [int(v) for v in out]
+
+
+def decode_scalar_pvw_host(params: PvwParameters, noisy: np.ndarray) -> List[int]:
+    """The same decode with host big integers (no GPU): cross-check of the device algorithm."""
+    a = _u64(noisy).reshape(-1, params.L, params.l)
+    out = np.zeros(len(a), dtype=np.uint64)
+    _check(_ffi.lib().pvw_decode_host(params._h, _ptr(a), len(a), _ptr(out)))
     return [int(v) for v in out]

@@ -21,6 +21,7 @@
 #include "pvw_arith.h"
 #include "pvw_bignum.h"
 #include "pvw_chacha.h"
+#include "pvw_decode.h"
 #include "pvw_kernels.h"
 
 using namespace pvw;
@@ -132,6 +133,11 @@ struct pvw_ctx {
   std::vector<Mod> mods;
   std::vector<u64> tw, itw, linv, ghat, gpow;
   bool roots_locked = false;
+  // fixed-width decode tables (host copies; pvw_decode.h)
+  std::vector<u64> dec_words;      // all u64 tables back to back
+  DecodeTables dec_host{};         // pointers into dec_words
+  DecodeTables dec_dev{};          // pointers into d_dec
+  void* d_dec = nullptr;
 
   // device state
   bool dev_ready = false;
@@ -207,6 +213,68 @@ static void build_tables(pvw_ctx* c) {
   }
 }
 
+// ---- decode tables (pvw_decode.h): big constants as W little-endian words ----
+static void bn_words(const BigInt& v, size_t W, u64* out) {
+  for (size_t i = 0; i < W; ++i) out[i] = i < v.mag.size() ? v.mag[i] : 0;
+}
+static void build_decode_tables(pvw_ctx* c) {
+  const size_t L = c->L;
+  const size_t W = (c->Q.bits() + 8 + 63) / 64;
+  // layout (u64 words): Q | halfQ | qi[L][W] | inv[L] | invp[L] | pow64[L][W] | dmod[L] | dmodp[L] |
+  //                     delta | dpow | half_dpow | dpow_n | td_n
+  const size_t total = 2 * W + L * W + 2 * L + L * W + 2 * L + 5 * W + W * L + 3 * (W + 2);
+  c->dec_words.assign(total, 0);
+  u64* p = c->dec_words.data();
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += n; return o; };
+  const size_t oQ = take(W), oH = take(W), oQi = take(L * W), oInv = take(L), oInvp = take(L), oPow = take(L * W),
+               oDm = take(L), oDmp = take(L), oDelta = take(W), oDpow = take(W), oHalfD = take(W), oDpn = take(W), oTdn = take(W),
+               oPowT = take(W * L), oTd = take(W + 2), oMuTd = take(W + 2), oMuDp = take(W + 2);
+  bn_words(c->Q, W, p + oQ);
+  bn_words(c->halfQ, W, p + oH);
+  for (size_t i = 0; i < L; ++i) {
+    const Mod& m = c->mods[i];
+    bn_words(c->crt_qi[i], W, p + oQi + i * W);
+    p[oInv + i] = c->crt_inv[i];
+    p[oInvp + i] = shoup_precompute(c->crt_inv[i], m.q);
+    u64 b = powmod(2, 64, m), cur = 1;
+    for (size_t j = 0; j < W; ++j) { p[oPow + i * W + j] = cur; cur = mulmod(cur, b, m); }
+    u64 dm = c->delta.mod_small(m.q);
+    p[oDm + i] = dm;
+    p[oDmp + i] = shoup_precompute(dm, m.q);
+  }
+  for (size_t i = 0; i < L; ++i)
+    for (size_t j = 0; j < W; ++j) p[oPowT + j * L + i] = p[oPow + i * W + j];
+  {
+    BigInt td = c->delta * BigInt(2), bw1 = BigInt(1).shl(64 * (W + 1));
+    bn_words(td, W + 2, p + oTd);
+    bn_words(bw1 / td, W + 2, p + oMuTd);
+    bn_words(bw1 / c->delta_pow, W + 2, p + oMuDp);
+  }
+  bn_words(c->delta, W, p + oDelta);
+  bn_words(c->delta_pow, W, p + oDpow);
+  bn_words(c->delta_pow.shr(1), W, p + oHalfD);
+  auto norm = [&](const BigInt& v, u64* dst, u32& nw, u32& sh) {
+    nw = (u32)v.mag.size();
+    sh = (u32)__builtin_clzll(v.mag.back());
+    bn_words(v.shl(sh), W, dst);
+  };
+  DecodeTables t{};
+  t.W = (u32)W; t.L = c->L; t.ell = c->l;
+  norm(c->delta_pow, p + oDpn, t.dpow_nw, t.dpow_sh);
+  norm(c->delta * BigInt(2), p + oTdn, t.td_nw, t.td_sh);
+  auto bind = [&](DecodeTables& d, const u64* base, const Mod* mods) {
+    d = t;
+    d.mods = mods;
+    d.Q = base + oQ; d.halfQ = base + oH; d.qi = base + oQi; d.inv = base + oInv; d.invp = base + oInvp;
+    d.pow64 = base + oPow; d.dmod = base + oDm; d.dmodp = base + oDmp; d.delta = base + oDelta;
+    d.dpow = base + oDpow; d.half_dpow = base + oHalfD; d.dpow_n = base + oDpn; d.td_n = base + oTdn;
+    d.pow64T = base + oPowT; d.td = base + oTd; d.mu_td = base + oMuTd; d.mu_dp = base + oMuDp;
+  };
+  bind(c->dec_host, p, c->mods.data());
+  c->dec_dev = t;   // pointers bound at upload
+}
+
 static int32_t upload_tables(pvw_ctx* c) {
   const size_t L = c->L, l = c->l;
   const size_t bytes = L * sizeof(Mod) + 8 * L * l * 8 + 2 * L * 8;
@@ -237,6 +305,21 @@ static int32_t upload_tables(pvw_ctx* c) {
   c->dt.ghatp = (const u64*)put(ghatp.data(), L * l * 8);
   c->dt.gpowp = (const u64*)put(gpowp.data(), L * l * 8);
   c->dt.linvp = (const u64*)put(linvp.data(), L * 8);
+  // decode tables
+  if (!c->d_dec) PVW_HIP(hipMalloc(&c->d_dec, c->dec_words.size() * 8));
+  PVW_HIP(hipMemcpy(c->d_dec, c->dec_words.data(), c->dec_words.size() * 8, hipMemcpyHostToDevice));
+  {
+    const u64* hb = c->dec_words.data();
+    const u64* db = (const u64*)c->d_dec;
+    DecodeTables d = c->dec_host;
+    auto mv = [&](const u64* hp) { return db + (hp - hb); };
+    d.mods = c->dt.mods;
+    d.Q = mv(d.Q); d.halfQ = mv(d.halfQ); d.qi = mv(d.qi); d.inv = mv(d.inv); d.invp = mv(d.invp); d.pow64 = mv(d.pow64);
+    d.dmod = mv(d.dmod); d.dmodp = mv(d.dmodp); d.delta = mv(d.delta); d.dpow = mv(d.dpow); d.half_dpow = mv(d.half_dpow);
+    d.dpow_n = mv(d.dpow_n); d.td_n = mv(d.td_n);
+    d.pow64T = mv(d.pow64T); d.td = mv(d.td); d.mu_td = mv(d.mu_td); d.mu_dp = mv(d.mu_dp);
+    c->dec_dev = d;
+  }
   PVW_HIP(hipDeviceSynchronize());
   return PVW_OK;
 }
@@ -427,6 +510,7 @@ int32_t pvw_ctx_create(const pvw_params_t* p, pvw_ctx** out) {
     c->crt_inv.push_back(powmod(qi.mod_small(c->moduli[i]), c->moduli[i] - 2, c->mods[i]));
   }
   build_tables(c);
+  build_decode_tables(c);
   *out = c;
   return PVW_OK;
 }
@@ -442,6 +526,7 @@ int32_t pvw_ctx_destroy(pvw_ctx* c) {
     hipFree(c->dA);
     hipFree(c->dB);
     hipFree(c->d_tables);
+    hipFree(c->d_dec);
     if (c->stream) hipStreamDestroy(c->stream);
   }
   delete c;
@@ -1199,7 +1284,7 @@ static uint64_t decode_one(const pvw_ctx* c, const uint64_t* noisy) {   // decry
   return plain.fits_u64() ? plain.low_u64() : 0;
 }
 
-int32_t pvw_decode(const pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* out) {
+int32_t pvw_decode_host(const pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* out) {
   if (!c || ((!noisy || !out) && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   const size_t P = c->poly();
   unsigned nt = std::thread::hardware_concurrency();
@@ -1216,6 +1301,50 @@ int32_t pvw_decode(const pvw_ctx* c, const uint64_t* noisy, size_t count, uint64
       for (size_t d = t; d < count; d += nt) out[d] = decode_one(c, noisy + d * P);
     });
   for (auto& x : th) x.join();
+  return PVW_OK;
+}
+
+// host execution of the fixed-width decode that the GPU runs (pvw_decode.h) -- a SELF-TEST hook so
+// the device algorithm can be checked on a machine without a GPU; not used by any product path.
+int32_t pvw_selftest_decode_fixed(const pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* out) {
+  if (!c || ((!noisy || !out) && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  const DecodeTables& t = c->dec_host;
+  std::vector<u64> x(t.W + 1), y(t.W), nres(t.L);
+  for (size_t d = 0; d < count; ++d)
+    out[d] = decode_one_fixed(t, noisy + d * c->poly(), BN{x.data(), 1}, BN{y.data(), 1}, BN{nres.data(), 1});
+  return PVW_OK;
+}
+
+// decode_scalar_pvw_rns on the device, host buffers in and out
+int32_t pvw_decode(pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* out) {
+  if (!c || ((!noisy || !out) && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (count == 0) return PVW_OK;
+  PVW_TRY(ensure_device(c));
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  const size_t inb = (count * c->poly() * 8 + 255) & ~(size_t)255;
+  int32_t rc = ws_scratch(w, inb + count * 8);
+  if (rc == PVW_OK) {
+    char* base = (char*)w->scratch;
+    if (hipMemcpyAsync(base, noisy, count * c->poly() * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+    if (rc == PVW_OK) {
+      ProfScope ps(c, "decode", w->stream);
+      if (launch_decode((const u64*)base, (u64*)(base + inb), count, c->dec_dev, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "decode launch failed");
+    }
+    if (rc == PVW_OK && (hipMemcpyAsync(out, base + inb, count * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                         hipStreamSynchronize(w->stream) != hipSuccess)) rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  }
+  ws_release(c, w);
+  return rc;
+}
+
+int32_t pvw_decode_device(pvw_ctx* c, const uint64_t* d_noisy, size_t count, uint64_t* d_out, void* stream) {
+  if (!c || ((!d_noisy || !d_out) && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (count == 0) return PVW_OK;
+  PVW_TRY(ensure_device(c));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  ProfScope ps(c, "decode", s);
+  PVW_HIP(launch_decode(d_noisy, d_out, count, c->dec_dev, s));
   return PVW_OK;
 }
 
@@ -1275,16 +1404,15 @@ int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, co
   const size_t b_sk = (k * l * 8 + 255) & ~(size_t)255;
   const size_t b_c1 = (per * k * P * 8 + 255) & ~(size_t)255;
   const size_t b_c2 = (per * P * 8 + 255) & ~(size_t)255;
-  int32_t rc = ws_scratch(w, b_sk + b_c1 + 2 * b_c2);
-  std::vector<uint64_t> noisy_host;
-  uint64_t* nz = noisy_out;
-  if (!nz) { noisy_host.resize(D * P); nz = noisy_host.data(); }
+  const size_t b_out = (per * 8 + 255) & ~(size_t)255;
+  int32_t rc = ws_scratch(w, b_sk + b_c1 + 2 * b_c2 + b_out);
   if (rc == PVW_OK) {
     char* base = (char*)w->scratch;
     i64* d_sk = (i64*)base;
     u64* d_c1 = (u64*)(base + b_sk);
     u64* d_c2 = (u64*)(base + b_sk + b_c1);
     u64* d_nz = (u64*)(base + b_sk + b_c1 + b_c2);
+    u64* d_out = (u64*)(base + b_sk + b_c1 + 2 * b_c2);
     if (hipMemcpyAsync(d_sk, sk, k * l * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "H2D failed");
     for (size_t d0 = 0; rc == PVW_OK && d0 < D; d0 += per) {
       const size_t cnt = (D - d0) < per ? (D - d0) : per;
@@ -1294,14 +1422,18 @@ int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, co
         break;
       }
       rc = decrypt_enqueue(c, w, d_sk, d_c1, d_c2, cnt, in_repr, d_nz, w->stream, true);
-      if (rc == PVW_OK && (hipMemcpyAsync(nz + d0 * P, d_nz, cnt * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+      if (rc == PVW_OK) {
+        ProfScope ps(c, "decode", w->stream);
+        if (launch_decode(d_nz, d_out, cnt, c->dec_dev, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "decode launch failed");   // decryption.rs:277
+      }
+      if (rc == PVW_OK && (hipMemcpyAsync(out_u64 + d0, d_out, cnt * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                           (noisy_out && hipMemcpyAsync(noisy_out + d0 * P, d_nz, cnt * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess) ||
                            hipStreamSynchronize(w->stream) != hipSuccess))
         rc = fail(PVW_ERR_INTERNAL, "D2H failed");
     }
   }
   ws_release(c, w);
-  if (rc != PVW_OK) return rc;
-  return pvw_decode(c, nz, D, out_u64);
+  return rc;
 }
 
 // ------------------------------------------------------------------------ key generation

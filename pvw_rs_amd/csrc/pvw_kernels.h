@@ -4,6 +4,7 @@
 
 #include "pvw_arith.h"
 #include "pvw_chacha.h"
+#include "pvw_decode.h"
 
 namespace pvw {
 
@@ -100,5 +101,7 @@ hipError_t launch_gaussian(i64* out, const ChaChaKey& key, u32 index0, u32 count
 hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col, u64* noisy,
                               const DevTables& t, u32 k, u32 L, u32 ell, size_t dealers,
                               hipStream_t s);
+
+hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s);
 
 }  // namespace pvw

@@ -22,6 +22,7 @@
 
 #include "pvw_arith.h"
 #include "pvw_chacha.h"
+#include "pvw_decode.h"
 #include "pvw_kernels.h"
 
 namespace pvw {
@@ -708,6 +709,253 @@ __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __
 }
 
 // ------------------------------------------------------------------------------------
+// decode: decode_scalar_pvw_rns (decryption.rs:10-58) on the device, one thread per ciphertext.
+// Big integers live in LDS with the thread index as the fast axis (word j of thread t at [j][t]).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void decode_kernel(const u64* __restrict__ noisy, u64* __restrict__ out,
+                                                     u32 count, DecodeTables t) {
+  extern __shared__ u64 dsm[];
+  const u32 d = blockIdx.x * 64 + threadIdx.x;
+  u64* base = dsm + threadIdx.x;
+  BN x{base, 64};
+  BN y{base + (size_t)(t.W + 1) * 64, 64};
+  BN nres{base + (size_t)(2 * t.W + 1) * 64, 64};
+  if (d >= count) return;
+  out[d] = decode_one_fixed(t, noisy + (size_t)d * t.L * t.ell, x, y, nres);
+}
+
+// ------------------------------------------------------------------------------------
+// decode, wave-cooperative form: ONE WAVE per ciphertext.  A big integer lives one 64-bit word
+// per lane (word w in lane w), an RNS value one limb per lane; every step of pvw_decode.h's
+// algorithm becomes "per-lane column sums + a short cross-lane carry loop":
+//   lift      x = sum_i t_i * (Q/q_i) - kq*Q          L broadcast steps, columns of 3 words
+//   to RNS    r_limb = sum_j x_j * 2^(64 j) mod q      W broadcast steps, lazy accumulator
+//   divide    q^ = floor(N * floor(B^(W+1)/d) / B^(W+1)) from the top W+2 columns only, then
+//             at most two corrections against the exact remainder (no digit-serial long division)
+// Needs L <= 64 and W + 2 <= 64 (Q up to ~3900 bits); otherwise launch_decode uses decode_kernel.
+// ------------------------------------------------------------------------------------
+struct WaveBN {
+  u64 x;   // this lane's word
+};
+__device__ __forceinline__ u64 shfl_up_u64(u64 v, int delta, u32 lane) {
+  u32 lo = __shfl_up((u32)v, delta), hi = __shfl_up((u32)(v >> 32), delta);
+  u64 r = ((u64)hi << 32) | lo;
+  return lane >= (u32)delta ? r : 0;
+}
+// columns (c0 + c1*B + c2*B^2 at weight lane) -> one word per lane
+__device__ __forceinline__ u64 wave_normalize(u64 c0, u64 c1, u64 c2, u32 lane) {
+  u64 b = shfl_up_u64(c1, 1, lane), c = shfl_up_u64(c2, 2, lane);
+  u64 s = c0 + b;
+  u64 k = s < b;
+  s += c;
+  k += s < c;
+  while (__ballot(k != 0)) {
+    u64 kin = shfl_up_u64(k, 1, lane);
+    s += kin;
+    k = s < kin;
+  }
+  return s;
+}
+// x - y for x >= y (both one word per lane)
+__device__ __forceinline__ u64 wave_sub(u64 x, u64 y, u32 lane) {
+  u64 d = x - y;
+  u64 b = x < y;
+  while (__ballot(b != 0)) {
+    u64 bin = shfl_up_u64(b, 1, lane);
+    b = d < bin;
+    d -= bin;
+  }
+  return d;
+}
+// three-way compare of two lane-distributed integers: >0, 0, <0
+__device__ __forceinline__ int wave_cmp(u64 x, u64 y) {
+  unsigned long long g = __ballot(x > y), l = __ballot(x < y);
+  return g > l ? 1 : (g == l ? 0 : -1);
+}
+__device__ __forceinline__ void col_mac(u64& c0, u64& c1, u64& c2, u64 a, u64 b) {
+  u128 p = (u128)a * b;
+  u64 lo = (u64)p, hi = (u64)(p >> 64);
+  c0 += lo;
+  u64 k = c0 < lo;
+  hi += k;               // hi <= 2^64 - 2, cannot wrap
+  c1 += hi;
+  c2 += c1 < hi;
+}
+
+struct WaveDecodeCtx {
+  const DecodeTables& t;
+  u64* xs;     // per-wave LDS scratch, 64 words
+  u32 lane;
+  u32 W, L;
+  Mod m;       // this lane's limb modulus (lanes >= L: limb 0, masked out by `limb_on`)
+  bool limb_on, word_on;
+  u64 Qw, halfQw;
+};
+
+// CRT lift of one residue per limb-lane to x in [0, Q), centred: |value| one word per lane, sign returned
+__device__ __forceinline__ u64 wave_lift_centered(const WaveDecodeCtx& c, u64 res, bool& neg) {
+  const DecodeTables& t = c.t;
+  const u32 lane = c.lane;
+  u64 ti = c.limb_on ? mulmod_shoup(res, t.inv[lane], t.invp[lane], c.m.q) : 0;
+  // fixed-point t_i / q_i (error < 2 ulp, from below) to predict how many multiples of Q the sum holds
+  u64 f = c.limb_on ? ti * c.m.ratio_hi + mulhi64(ti, c.m.ratio_lo) : 0;
+  c.xs[lane] = ti;
+  // wave sum of the 64-bit fractions as a 128-bit value
+  u64 flo = f, fhi = 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    u64 olo = ((u64)__shfl_xor((u32)(flo >> 32), d) << 32) | __shfl_xor((u32)flo, d);
+    u64 ohi = ((u64)__shfl_xor((u32)(fhi >> 32), d) << 32) | __shfl_xor((u32)fhi, d);
+    flo += olo;
+    fhi += ohi + (flo < olo);
+  }
+  const u64 kq = fhi;   // floor(sum t_i/q_i) or one less
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  u64 c0 = 0, c1 = 0, c2 = 0;
+  if (c.word_on) {
+    for (u32 i = 0; i < c.L; ++i) col_mac(c0, c1, c2, c.xs[i], t.qi[(size_t)i * c.W + lane]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  u64 x = wave_normalize(c0, c1, c2, lane);
+  // subtract kq * Q
+  {
+    u128 p = c.word_on ? (u128)kq * c.Qw : 0;
+    u64 y = wave_normalize((u64)p, (u64)(p >> 64), 0, lane);
+    x = wave_sub(x, y, lane);
+  }
+  while (wave_cmp(x, c.Qw) >= 0) x = wave_sub(x, c.Qw, lane);
+  neg = false;
+  if (wave_cmp(x, c.halfQw) > 0) {                 // decryption.rs:145-151
+    x = wave_sub(c.Qw, x, lane);
+    neg = true;
+  }
+  return x;
+}
+// |x| (one word per lane) mod q_limb for every limb-lane, sign applied
+__device__ __forceinline__ u64 wave_to_rns(const WaveDecodeCtx& c, u64 x, bool neg) {
+  c.xs[c.lane] = x;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  u64 r = 0;
+  if (c.limb_on) {
+    Acc acc;
+    acc_zero(acc);
+    for (u32 j = 0; j < c.W; ++j) acc_mac_dev(acc, c.xs[j], c.t.pow64T[(size_t)j * c.L + c.lane]);
+    r = acc_reduce(acc, c.m);
+    if (neg && r) r = c.m.q - r;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return r;
+}
+// floor(N / d) and N mod d via the reciprocal mu = floor(B^(W+1)/d); d given one word per lane (dw)
+// and as a table (dtab, W+2 words); mu as a table of W+2 words.  N < B^W.  Returns quotient in q, remainder in r.
+__device__ __forceinline__ void wave_divmod(const WaveDecodeCtx& c, u64 n, const u64* mu, const u64* dtab, u64 dw,
+                                            u64& q, u64& r) {
+  const u32 lane = c.lane, W = c.W;
+  c.xs[lane] = n;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // top W+2 columns of N * mu: lane v holds column W-1+v
+  u64 c0 = 0, c1 = 0, c2 = 0;
+  if (lane < W + 2) {
+    const u32 col = W - 1 + lane;
+    for (u32 i = 0; i < W; ++i) {
+      const u32 j = col - i;                       // index into mu
+      if (j < W + 2) col_mac(c0, c1, c2, c.xs[i], mu[j]);
+    }
+  }
+  u64 p = wave_normalize(c0, c1, c2, lane);        // lane v: word W-1+v of the (truncated) product
+  // quotient estimate = words W+1 .. 2W  -> lanes 2 .. W+1, moved down to lanes 0 .. W-1
+  {
+    u32 lo = __shfl_down((u32)p, 2), hi = __shfl_down((u32)(p >> 32), 2);
+    q = lane < W ? (((u64)hi << 32) | lo) : 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // remainder N - q*d (q <= true quotient, so this is >= 0)
+  c.xs[lane] = q;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  c0 = c1 = c2 = 0;
+  if (lane < W) {
+    for (u32 i = 0; i <= lane; ++i) {
+      const u32 j = lane - i;                      // index into d
+      col_mac(c0, c1, c2, c.xs[i], dtab[j < W + 2 ? j : W + 1]);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  u64 qd = wave_normalize(c0, c1, c2, lane);
+  qd = lane < W ? qd : 0;                          // the product fits W words (<= N)
+  r = wave_sub(n, qd, lane);
+  while (wave_cmp(r, dw) >= 0) {                   // at most two corrections
+    r = wave_sub(r, dw, lane);
+    u64 one = lane == 0 ? 1 : 0;
+    q = wave_normalize(q + one, (q + one) < one ? 1 : 0, 0, lane);
+  }
+}
+
+__global__ __launch_bounds__(256) void decode_wave_kernel(const u64* __restrict__ noisy, u64* __restrict__ out,
+                                                           u32 count, DecodeTables t) {
+  __shared__ u64 lds[4 * 64];
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32 d = blockIdx.x * 4 + wave;
+  if (d >= count) return;                           // whole waves exit together
+  const u32 W = t.W, L = t.L, l = t.ell;
+  WaveDecodeCtx c{t, lds + wave * 64, lane, W, L, t.mods[lane < L ? lane : 0], lane < L, lane < W,
+                  lane < W ? t.Q[lane] : 0, lane < W ? t.halfQ[lane] : 0};
+  const u64* z = noisy + (size_t)d * L * l + (size_t)(c.limb_on ? lane : 0) * l;   // this limb's l residues
+  const u64 dm = t.dmod[c.limb_on ? lane : 0], dmp = t.dmodp[c.limb_on ? lane : 0];
+  const u64 q = c.m.q;
+  auto tmp = [&](u32 i) -> u64 { return submod(mulmod_shoup(z[i], dm, dmp, q), z[i + 1], q); };   // :19-27
+  // Horner over tmp_0 .. tmp_{l-2} (:30-33)
+  u64 h = tmp(0);
+  for (u32 i = 1; i + 1 < l; ++i) h = addmod(mulmod_shoup(h, dm, dmp, q), tmp(i), q);
+  bool neg;
+  u64 x = wave_lift_centered(c, h, neg);
+  // reduce_modulo_poly (:154-178)
+  const u64 dpw = lane < W ? t.dpow[lane] : 0, hdw = lane < W ? t.half_dpow[lane] : 0;
+  u64 qq, r;
+  wave_divmod(c, x, t.mu_dp, t.dpow, dpw, qq, r);
+  if (__ballot(r != 0) == 0) neg = false;
+  if (wave_cmp(r, hdw) > 0) {
+    r = wave_sub(dpw, r, lane);
+    neg = !neg;
+  }
+  u64 nres = wave_to_rns(c, r, neg);
+  // noise[i] = round((noise[i+1] - tmp[i]) / Delta), i = l-2 .. 0   (:44-48, :180-207)
+  const u64 tdw = lane < W ? t.td[lane] : 0, dlw = lane < W ? t.delta[lane] : 0;
+  for (u32 i = l - 1; i-- > 0;) {
+    bool pneg;
+    u64 p = wave_lift_centered(c, submod(nres, tmp(i), q), pneg);
+    // 2|p| + Delta
+    u64 hi = p >> 63, lo2 = p << 1;
+    u64 s = lo2 + dlw;
+    u64 num = wave_normalize(s, hi + (s < dlw), 0, lane);
+    wave_divmod(c, num, t.mu_td, t.td, tdw, qq, r);
+    const bool qzero = __ballot(qq != 0) == 0;
+    nres = wave_to_rns(c, qq, pneg && !qzero);
+  }
+  // plaintext = -z_0 - noise_0 (:51-53), then extract_constant_term_as_u64 (:226-247)
+  bool vneg;
+  u64 z0 = z[0];
+  u64 v = wave_lift_centered(c, submod(z0 ? q - z0 : 0, nres, q), vneg);
+  const bool vzero = __ballot(v != 0) == 0;
+  u64 result;
+  if (vneg && !vzero) {
+    const bool hiw = __ballot(lane > 0 && v != 0) != 0;
+    const u64 v0 = ((u64)__shfl((u32)(v >> 32), 0) << 32) | (u32)__shfl((u32)v, 0);
+    if (!hiw && v0 <= 1000) {                       // small negative -> 0 (:233-235)
+      if (lane == 0) out[d] = 0;
+      return;
+    }
+    v = wave_sub(c.Qw, v, lane);                    // (v + Q) % Q = Q - |v|
+  }
+  const bool hiw2 = __ballot(lane > 0 && v != 0) != 0;
+  result = hiw2 ? 0 : v;
+  if (lane == 0) out[d] = result;
+}
+
+// ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
 #define PVW_DISPATCH_ELL(ell, ...)                       \
@@ -910,6 +1158,24 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
       default: decrypt_mac_kernel<4, true><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
     }
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  const size_t lds = (size_t)(2 * t.W + 1 + t.L) * 64 * sizeof(u64);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  static int variant = [] { const char* e = getenv("PVW_DECODE_VARIANT"); return e ? atoi(e) : 0; }();
+  if (variant == 0 && t.L <= 64 && t.W + 2 <= 64) {
+    decode_wave_kernel<<<dim3((u32)((count + 3) / 4)), dim3(256), 0, s>>>(noisy, out, (u32)count, t);
+    return hipGetLastError();
+  }
+  decode_kernel<<<dim3((u32)((count + 63) / 64)), dim3(64), lds, s>>>(noisy, out, (u32)count, t);
   return hipGetLastError();
 }
 

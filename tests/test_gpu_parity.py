@@ -334,6 +334,30 @@ def test_multi_dealer_encrypt_l16_and_sharded():
         assert not part[d].c1[:2].any() and not part[d].c2[8:].any()
 
 
+@pytest.mark.parametrize("l,moduli", [(8, [0xFFFFEE001]), (8, TEST_MODULI), (32, TEST_MODULI), (8, M.bench_moduli(17)),
+                                      (16, M.bench_moduli(34))])
+def test_device_decode_matches_model(l, moduli):
+    # decode_scalar_pvw_rns (decryption.rs:10-58) on the device, fixed-width integers
+    rng = np.random.default_rng(l + len(moduli))
+    p = build_params(3, 4, l, moduli)
+    m = M.Params(3, 4, l, moduli)
+    Q, D = m.Q, m.delta
+    cases = [[int.from_bytes(rng.bytes(Q.bit_length() // 8 + 8), "little") % Q for _ in range(l)] for _ in range(150)]
+    for msg in (0, 1, 1000, 1001, -1, -1000, -1001, 2 ** 32, 2 ** 63, 2 ** 64 - 1, 2 ** 64):
+        for amp in (0, 50, 10 ** 4):
+            noise = [int(x) for x in rng.integers(-amp, amp + 1, size=l)]
+            cases.append([(-(msg * D ** j) + noise[j]) % Q for j in range(l)])
+    half = Q // 2
+    for v in (0, 1, half - 1, half, half + 1, Q - 1, m.delta_power_l_minus_1 // 2, m.delta_power_l_minus_1 // 2 + 1,
+              m.delta_power_l_minus_1, D, D // 2, D // 2 + 1):
+        cases.append([v % Q] * l)
+        cases.append([(v * (j + 1)) % Q for j in range(l)])
+    arr = np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64)
+    got = P.decode_scalar_pvw(p, arr)
+    assert got == [M.decode_scalar_pvw(z, m) for z in cases]
+    assert got == P.decode_scalar_pvw_host(p, arr)
+
+
 def test_sharded_contexts_match_unsharded():
     # one process per GPU holds rows [party_lo, party_hi) of B and [c1_lo, c1_hi) of A
     n, k, l, moduli = 21, 12, 8, M.bench_moduli(3)

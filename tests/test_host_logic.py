@@ -104,7 +104,9 @@ def test_decode_matches_golden(path):
          .set_moduli([int(q) for q in z["moduli"]]).set_secret_variance(float(z["variance"]))
          .set_error_bounds(int(z["bound1"]), int(z["bound2"])).build())
     assert p.delta() == sum(int(w) << (64 * i) for i, w in enumerate(z["delta_words"]))
-    assert P.decode_scalar_pvw(p, z["noisy_pb"]) == [int(v) for v in z["decoded"]]
+    assert P.decode_scalar_pvw_host(p, z["noisy_pb"]) == [int(v) for v in z["decoded"]]
+    # the fixed-width algorithm the GPU runs (pvw_decode.h), executed on the host
+    assert P.api._selftest_decode_fixed(p, z["noisy_pb"]) == [int(v) for v in z["decoded"]]
 
 
 def test_decode_quirks_match_model():
@@ -120,7 +122,35 @@ def test_decode_quirks_match_model():
         for _ in range(20):   # random garbage polynomials must decode identically as well
             cases.append([int.from_bytes(rng.bytes(m.Q.bit_length() // 8 + 8), "little") % m.Q for _ in range(l)])
         arr = np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64)
-        assert P.decode_scalar_pvw(p, arr) == [M.decode_scalar_pvw(z, m) for z in cases]
+        want = [M.decode_scalar_pvw(z, m) for z in cases]
+        assert P.decode_scalar_pvw_host(p, arr) == want
+        assert P.api._selftest_decode_fixed(p, arr) == want
+
+
+@pytest.mark.parametrize("l,moduli", [(8, [0xFFFFEE001]), (8, TEST_MODULI), (32, TEST_MODULI), (8, EXAMPLE_MODULI),
+                                      (8, M.bench_moduli(17)), (16, M.bench_moduli(34))])
+def test_fixed_width_decode_matches_model_on_random_and_edge_inputs(l, moduli):
+    rng = np.random.default_rng(l * 1000 + len(moduli))
+    p = _builder(l=l, moduli=moduli).build()
+    m = M.Params(3, 4, l, moduli)
+    Q, D = m.Q, m.delta
+    cases = []
+    for _ in range(60):      # uniformly random polynomials: exercises every branch of the integer decode
+        cases.append([int.from_bytes(rng.bytes(Q.bit_length() // 8 + 8), "little") % Q for _ in range(l)])
+    for msg in (0, 1, 7, 1000, 1001, -1, -1000, -1001, 2 ** 32, 2 ** 63, 2 ** 64 - 1, 2 ** 64):
+        for amp in (0, 1, 50, 10 ** 4):
+            noise = [int(x) for x in rng.integers(-amp, amp + 1, size=l)]
+            cases.append([(-(msg * D ** j) + noise[j]) % Q for j in range(l)])
+    # boundary values of the centring / halving comparisons
+    half = Q // 2
+    for v in (0, 1, half - 1, half, half + 1, Q - 1, m.delta_power_l_minus_1 // 2, m.delta_power_l_minus_1 // 2 + 1,
+              m.delta_power_l_minus_1, D, D // 2, D // 2 + 1):
+        cases.append([v % Q] * l)
+        cases.append([(v * (j + 1)) % Q for j in range(l)])
+    arr = np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64)
+    want = [M.decode_scalar_pvw(z, m) for z in cases]
+    assert P.decode_scalar_pvw_host(p, arr) == want
+    assert P.api._selftest_decode_fixed(p, arr) == want
 
 
 def test_device_entry_points_fail_loudly_without_gpu():
