@@ -85,6 +85,19 @@ struct ChaChaRng {
 // Writes l coefficients through `emit(index, value)`.
 template <class Emit>
 PVW_HD void sample_cbd_poly(ChaChaRng& g, u32 l, bool half, u32 v, Emit emit) {
+  if (half && g.pos == 16) {
+    // block-aligned fast path (same words as the sequential draws below): coefficient 8b+i of a
+    // stream uses words 2i, 2i+1 of block b -- statically indexed, no per-draw bookkeeping
+    for (u32 s0 = 0; s0 < l; s0 += 8) {
+      g.refill();
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (s0 + i < l) emit(s0 + i, (i64)(g.buf[2 * i] & 1) - (i64)(g.buf[2 * i + 1] & 1));
+      const u32 used = (l - s0) < 8 ? 2 * (l - s0) : 16;
+      g.pos = (int)used;
+    }
+    return;
+  }
   if (half) {
     for (u32 s = 0; s < l; ++s) {
       i64 b1 = g.next_u32() & 1;
@@ -144,6 +157,27 @@ PVW_HD void sample_uniform_poly(ChaChaRng& g, u32 l, u64 bound, Emit emit) {
 #endif
   u32 digits = bits / 32, rem = bits % 32;
   u32 nwords = digits + (rem ? 1 : 0);
+  if (nwords == 1) {
+    // one word per draw (bounds below 2^31): walk the block with static word indices; rejected
+    // draws are skipped exactly as the sequential loop below would skip them
+    const u32 sh = rem ? 32 - rem : 0;
+    u32 s = 0;
+    while (s < l) {
+      if (g.pos == 16) g.refill();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i >= g.pos && s < l) {
+          const u32 w = g.buf[i] >> sh;
+          g.pos = i + 1;
+          if (w < (u32)range) {
+            emit(s, (i64)w - (i64)bound);
+            ++s;
+          }
+        }
+      }
+    }
+    return;
+  }
   for (u32 s = 0; s < l; ++s) {
     u64 v;
     do {

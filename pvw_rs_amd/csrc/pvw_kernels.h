@@ -81,6 +81,7 @@ struct PrologueBatch {
   ChaChaKey key[PVW_MAX_PROLOGUE_KEYS];
   u32 njobs;
   u32 total;   // filled in by the launcher
+  u32 debug;   // filled in by the launcher (timing experiments)
 };
 hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s);
 

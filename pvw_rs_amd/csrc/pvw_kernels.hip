@@ -438,8 +438,10 @@ __global__ __launch_bounds__(64) void sample_kernel(i64* __restrict__ out, ChaCh
 // polynomial, then one thread per (polynomial, limb) reduces, transforms and stores.
 // ------------------------------------------------------------------------------------
 template <int ELL>
-__global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u32 PB, DevTables t) {
-  __shared__ i64 sc[64 * ELL];
+__global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u32 PB, u32 stage_tables, DevTables t) {
+  extern __shared__ u64 psm[];
+  i64* sc = reinterpret_cast<i64*>(psm);              // [PB][ELL] sampled coefficients
+  u64* tab = psm + (size_t)PB * ELL;                  // [4][L][ELL] tw | twp | ghat | ghatp (if staged)
   const u32 gp0 = blockIdx.x * PB;
   const u32 tid = threadIdx.x;
   // locate (job, local polynomial) of global polynomial gp: jobs are laid end to end
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
     for (u32 x = 0; x + 1 < PVW_MAX_PROLOGUE_JOBS; ++x)
       if (ji == x && x + 1 < b.njobs && local >= b.job[x].sj.count) { local -= b.job[x].sj.count; ji = x + 1; }
   };
-  if (tid < PB && gp0 + tid < b.total) {
+  if (tid < PB && gp0 + tid < b.total && !(b.debug & 1)) {
     u32 ji, local;
     locate(gp0 + tid, ji, local);
     const PrologueJob& job = b.job[ji];
@@ -465,22 +467,34 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
       if (job.sj.kind == SAMPLE_CBD) sample_cbd_poly(g, ELL, job.sj.cbd_half != 0, job.sj.cbd_v, emit);
       else sample_uniform_poly(g, ELL, job.sj.bound, emit);
     }
+  } else if (stage_tables && tid >= 64) {
+    // the three waves that do not sample bring the twiddle / gadget tables into LDS meanwhile
+    const u32 n = L * ELL;
+    for (u32 x = tid - 64; x < n; x += 192) {
+      tab[x] = t.tw[x];
+      tab[n + x] = t.twp[x];
+      tab[2 * n + x] = t.ghat[x];
+      tab[3 * n + x] = t.ghatp[x];
+    }
   }
   __syncthreads();
   const u32 p = tid / L, limb = tid % L;
-  if (p >= PB || gp0 + p >= b.total) return;
+  if (p >= PB || gp0 + p >= b.total || (b.debug & 2)) return;
   u32 ji, local;
   locate(gp0 + p, ji, local);
   const PrologueJob& job = b.job[ji];
   const Mod m = t.mods[limb];
+  const u32 n = L * ELL;
+  const u64* tw = stage_tables ? tab + (size_t)limb * ELL : t.tw + (size_t)limb * ELL;
+  const u64* twp = stage_tables ? tab + n + (size_t)limb * ELL : t.twp + (size_t)limb * ELL;
   u64 a[ELL];
 #pragma unroll
   for (int s = 0; s < ELL; ++s) a[s] = signed_residue(sc[p * ELL + s], m);
-  ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, m);
+  ntt_forward<ELL>(a, tw, twp, m);
   if (job.scalars) {
     const u64 mr = signed_residue((i64)job.scalars[local], m);   // `as i64` wrap, encryption.rs:195
-    const u64* g = t.ghat + (size_t)limb * ELL;
-    const u64* gp = t.ghatp + (size_t)limb * ELL;
+    const u64* g = stage_tables ? tab + 2 * n + (size_t)limb * ELL : t.ghat + (size_t)limb * ELL;
+    const u64* gp = stage_tables ? tab + 3 * n + (size_t)limb * ELL : t.ghatp + (size_t)limb * ELL;
 #pragma unroll
     for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod_shoup(mr, g[s], gp[s], m.q), m.q);
   }
@@ -1082,6 +1096,8 @@ hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJo
 hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s) {
   PrologueBatch b = batch;
   b.total = 0;
+  static u32 dbg = [] { const char* e = getenv("PVW_PROLOGUE_DEBUG"); return e ? (u32)atoi(e) : 0u; }();
+  b.debug = dbg;   // timing experiments only: 1 = skip sampling, 2 = skip transform
   if (b.njobs > PVW_MAX_PROLOGUE_JOBS) return hipErrorInvalidValue;
   for (u32 i = 0; i < b.njobs; ++i) b.total += b.job[i].sj.count;
   if (b.total == 0) return hipSuccess;
@@ -1089,7 +1105,10 @@ hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L
   u32 PB = 256 / L;
   if (PB > 64) PB = 64;
   const u32 blocks = (b.total + PB - 1) / PB;
-  PVW_DISPATCH_ELL(ell, prologue_kernel<E><<<dim3(blocks), dim3(256), 0, s>>>(b, L, PB, t));
+  const size_t sc_bytes = (size_t)PB * ell * 8, tab_bytes = (size_t)4 * L * ell * 8;
+  const u32 stage = (sc_bytes + tab_bytes <= 64 * 1024) ? 1u : 0u;
+  const size_t lds = sc_bytes + (stage ? tab_bytes : 0);
+  PVW_DISPATCH_ELL(ell, prologue_kernel<E><<<dim3(blocks), dim3(256), lds, s>>>(b, L, PB, stage, t));
   return hipGetLastError();
 }
 

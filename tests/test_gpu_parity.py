@@ -383,6 +383,42 @@ def test_sharded_contexts_match_unsharded():
     assert np.array_equal(c1, ct.c1) and np.array_equal(c2, ct.c2)
 
 
+def test_config4_geometry_keygen_encrypt_decrypt():
+    # BASELINE configs[3]/[4] geometry (k=512, l=16, 34 limbs = 2074-bit Q) at a party count the CPU
+    # oracle finishes in seconds: keygen, encrypt and batched decrypt bit-exact vs the C restatement,
+    # then the full round trip through the on-device decode.
+    n, k, l, L = 24, 512, 16, 34
+    moduli = M.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    assert p.q_total().bit_length() == 2074 and p.verify_correctness_condition()
+    seed = bytes([0xC4]) * 32
+    crs = P.PvwCrs.new_deterministic(p, seed)
+    gpk = P.GlobalPublicKey.new(crs)
+    parties = [P.Party.new(i, p, seed) for i in range(n)]
+    gpk.generate_all_party_keys(parties, seed)
+    orc = O.Oracle(moduli, l)
+    a_hat = crs.matrix(P.REPR_NTT)
+    assert np.array_equal(a_hat, orc.fill_uniform(seed, M.DOM_CRS, 0, k * k).reshape(k, k, L, l))
+    sk = np.stack([pt.secret_key.secret_coeffs for pt in parties])
+    assert np.array_equal(sk, O.sample_cbd(seed, M.DOM_SK, 0, n * k, l, 0.5).reshape(n, k, l))
+    ek = O.sample_uniform(seed, M.DOM_EKEY, 0, n * k, l, 100).reshape(n, k, l)
+    b_hat = gpk.matrix(repr=P.REPR_NTT)
+    assert np.array_equal(b_hat, orc.keygen(a_hat, sk, ek))
+    scalars = np.array([(i * 1000 + 1) % (1 << 32) for i in range(n)], dtype=np.uint64)
+    ct = P.encrypt(scalars, gpk, seed)
+    r = O.sample_cbd(seed, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(seed, M.DOM_E1, 0, k, l, 100)
+    e2 = O.sample_uniform(seed, M.DOM_E2, 0, n, l, 200)
+    c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), scalars, r, e1, e2)
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+    got = []
+    for i in range(n):
+        vals, noisy = P.api._decrypt_batch(p, [ct], parties[i].secret_key, i, return_noisy=True)
+        assert np.array_equal(noisy, orc.decrypt_noisy(sk[i], ct.c1[None], ct.c2[i][None]))
+        got.append(vals[0])
+    assert got == [int(x) for x in scalars]
+
+
 def test_config2_full_size_against_c_oracle():
     # BASELINE.json configs[1]: n=1024, k=256, l=8, 17 limbs (1037-bit Q), bit-exact vs the CPU path
     n, k, l, L = 1024, 256, 8, 17
