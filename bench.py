@@ -82,13 +82,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        # RCCL ("nccl") over xGMI in production; PVW_BENCH_BACKEND=gloo only to rehearse the N>1 code path
+        # on a box with fewer GPUs than ranks (see PVW_BENCH_SAME_DEVICE below)
+        dist.init_process_group(backend=os.environ.get("PVW_BENCH_BACKEND", "nccl"))
     if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
         print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available() or not P.device_available():
         print("bench.py needs a gfx950 GPU: the PVW hot path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if os.environ.get("PVW_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0                     # rehearsal: every rank on cuda:0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

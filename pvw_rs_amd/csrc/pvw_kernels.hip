@@ -156,6 +156,134 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
   }
 }
 
+// mac_rows, continuous-stream schedule: the B-hat tile stream of a wave never drains at an r-hat chunk
+// boundary.  The r-hat slice of the NEXT chunk is fetched into registers one group ahead (so its loads
+// sit in front of the tile prefetch in the in-order vmcnt queue) and dropped into the wave-private LDS
+// slab when the current chunk has been consumed.
+template <int ELL, int U, bool NT>
+__global__ __launch_bounds__(256) void mac_rows_stream_kernel(MacSection sa, MacSection sb,
+                                                               const u64* __restrict__ rhat,
+                                                               const Mod* __restrict__ mods, u32 k, u32 L) {
+  constexpr int HALF = ELL / 2;
+  constexpr int R = 128 / ELL;
+  constexpr int JC = ELL <= 16 ? 64 : (ELL == 32 ? 32 : 16);
+  constexpr int RN = JC * HALF / 64;          // 16-byte r-hat elements per lane per chunk
+  static_assert(JC % U == 0, "a group of U tiles must not straddle an r-hat chunk");
+  __shared__ v2u64 lds[4 * JC * HALF];
+
+  const u32 limb = blockIdx.x % L;
+  const u32 rbg = blockIdx.x / L;
+  const bool in_a = rbg < sa.row_blocks;
+  const u32 rb = in_a ? rbg : rbg - sa.row_blocks;
+  const u64* __restrict__ M = in_a ? sa.M : sb.M;
+  const u64* addend = in_a ? sa.addend : sb.addend;
+  u64* out = in_a ? sa.out : sb.out;
+  const u32 nrows = in_a ? sa.nrows : sb.nrows;
+
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 sp = lane % HALF, rho = lane / HALF;
+  const u32 kq = (k + 3) / 4;
+  const u32 j0 = wave * kq < k ? wave * kq : k;
+  const u32 j1 = (j0 + kq) < k ? (j0 + kq) : k;
+  const u32 total = j1 - j0;
+
+  const v2u64* mp = reinterpret_cast<const v2u64*>(M + ((size_t)rb * L + limb) * (size_t)k * 128) + lane + (size_t)j0 * 64;
+  const v2u64* rp = reinterpret_cast<const v2u64*>(rhat + (size_t)limb * k * ELL) + (size_t)j0 * HALF;
+  v2u64* lw = lds + wave * (JC * HALF);
+  auto ld = [&](size_t tile) -> v2u64 {
+    if constexpr (NT) return __builtin_nontemporal_load(mp + tile * 64);
+    else return mp[tile * 64];
+  };
+  // r-hat chunk starting at local tile `base` -> registers (clamped reads past the end are never used)
+  auto fetch_r = [&](u32 base, v2u64 (&rn)[RN]) {
+#pragma unroll
+    for (int x = 0; x < RN; ++x) {
+      u32 idx = base * HALF + lane + 64 * x;
+      u32 lim = total * HALF;
+      rn[x] = rp[idx < lim ? idx : (lim ? lim - 1 : 0)];
+    }
+  };
+  auto store_r = [&](const v2u64 (&rn)[RN]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int x = 0; x < RN; ++x) lw[lane + 64 * x] = rn[x];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  Acc a0, a1;
+  acc_zero(a0);
+  acc_zero(a1);
+  const u32 G = total / U;
+  v2u64 x[U], xn[U], rn[RN];
+  if (total) fetch_r(0, rn);
+  if (G) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = ld(u);
+  }
+  if (total) store_r(rn);
+  u32 chunk_base = 0;
+  for (u32 g = 0; g < G; ++g) {
+    const u32 t0 = g * U;
+    const bool last_of_chunk = ((t0 + U) % JC) == 0 && (t0 + U) < total;
+    if (last_of_chunk) fetch_r(t0 + U, rn);            // ahead of the tile prefetch in the load queue
+    if (g + 1 < G) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) xn[u] = ld(t0 + U + u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v2u64 y = lw[(t0 - chunk_base + u) * HALF + sp];
+      acc_mac_dev(a0, x[u].x, y.x);
+      acc_mac_dev(a1, x[u].y, y.y);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = xn[u];
+    if (last_of_chunk) {
+      store_r(rn);
+      chunk_base = t0 + U;
+    }
+  }
+  for (u32 jj = G * U; jj < total; ++jj) {                // ragged tail (k not a multiple of 4*U)
+    if (jj - chunk_base >= (u32)JC) {
+      fetch_r(jj, rn);
+      store_r(rn);
+      chunk_base = jj;
+    }
+    v2u64 xv = mp[(size_t)jj * 64];
+    v2u64 y = lw[(jj - chunk_base) * HALF + sp];
+    acc_mac_dev(a0, xv.x, y.x);
+    acc_mac_dev(a1, xv.y, y.y);
+  }
+
+  const Mod m = mods[limb];
+  v2u64 part;
+  part.x = acc_reduce(a0, m);
+  part.y = acc_reduce(a1, m);
+  __syncthreads();
+  lds[wave * 64 + lane] = part;
+  __syncthreads();
+  if (wave == 0) {
+    const u32 row = rb * R + rho;
+    if (row < nrows) {
+      v2u64 s = lds[lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        v2u64 t = lds[w * 64 + lane];
+        s.x = addmod(s.x, t.x, m.q);
+        s.y = addmod(s.y, t.y, m.q);
+      }
+      const size_t o = (((size_t)row * L + limb) * ELL) / 2 + sp;
+      if (addend) {
+        v2u64 e = reinterpret_cast<const v2u64*>(addend)[o];
+        s.x = addmod(s.x, e.x, m.q);
+        s.y = addmod(s.y, e.y, m.q);
+      }
+      reinterpret_cast<v2u64*>(out)[o] = s;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // mac_rows_multi: NV vectors against one pass over the tiled matrix,
 //     out_v[row] = sum_j M[row][j] * vhat_v[j] + addend_v[row],   v < NV.
@@ -984,6 +1112,7 @@ __global__ __launch_bounds__(256) void decode_wave_kernel(const u64* __restrict_
 // PVW_MAC_VARIANT (debug/tuning): selects the streaming schedule of mac_rows for l = 8 / 16
 //   0 (default) U=8 double-buffered nt | 1 same, default cache policy | 2 U=4 dbuf nt | 3 U=16 dbuf nt
 //   4 U=16 single buffer nt | 5 U=8 single buffer nt | 6 U=16 single buffer, default policy
+//   7 continuous stream U=8 nt | 8 continuous stream U=16 nt
 static int mac_variant() {
   static int v = [] {
     const char* e = getenv("PVW_MAC_VARIANT");
@@ -1002,8 +1131,16 @@ static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacS
       case 4: mac_rows_kernel<E, 16, true, false><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       case 5: mac_rows_kernel<E, 8, true, false><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       case 6: mac_rows_kernel<E, 16, false, false><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      case 7: mac_rows_stream_kernel<E, 8, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      case 8: mac_rows_stream_kernel<E, 16, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       default: break;
     }
+  }
+  // defaults from the round-1 sweep (profiles/r01_variant_sweep.txt): 8 tiles per buffer at l = 8,
+  // 16 at l >= 16 (longer per-workgroup streams), always double-buffered non-temporal loads
+  if constexpr (E == 16) {
+    mac_rows_kernel<E, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L);
+    return;
   }
   mac_rows_kernel<E, 8, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L);
 }
