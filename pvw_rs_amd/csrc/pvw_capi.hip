@@ -8,6 +8,7 @@
 // gate (:510-551) and the integer gadget decode (src/crypto/decryption.rs:10-247).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -140,7 +141,7 @@ struct pvw_ctx {
   void* d_dec = nullptr;
 
   // device state
-  bool dev_ready = false;
+  std::atomic<bool> dev_ready{false};
   void* d_tables = nullptr;
   DevTables dt{};
   u64* dA = nullptr;  // tiled A-hat rows [c1_lo, c1_hi)
@@ -149,7 +150,7 @@ struct pvw_ctx {
   u32 num_keys = 0;
   hipStream_t stream = nullptr;
 
-  std::mutex mu;
+  std::mutex mu, init_mu;
   std::vector<Workspace*> pool;
   std::map<void*, Workspace*> async_ws;
 
@@ -325,6 +326,11 @@ static int32_t upload_tables(pvw_ctx* c) {
 }
 
 static int32_t ensure_device(pvw_ctx* c) {
+  if (c->dev_ready) {
+    PVW_HIP(hipSetDevice(c->device));
+    return PVW_OK;
+  }
+  std::lock_guard<std::mutex> init_guard(c->init_mu);   // concurrent first calls initialise once
   if (c->dev_ready) {
     PVW_HIP(hipSetDevice(c->device));
     return PVW_OK;

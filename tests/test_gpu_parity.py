@@ -358,6 +358,38 @@ def test_device_decode_matches_model(l, moduli):
     assert got == P.decode_scalar_pvw_host(p, arr)
 
 
+def test_concurrent_encrypt_calls_on_one_context():
+    # the reference calls encrypt concurrently from rayon workers (encryption.rs:277-283); host-buffer
+    # ABI calls must be safe to issue concurrently on one context (ctypes releases the GIL)
+    import threading
+    n, k, l, moduli = 40, 16, 8, M.bench_moduli(3)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    jobs = [([(d * 100 + j) for j in range(n)], P.api._dealer_seed(SEED, d)) for d in range(24)]
+    want = [P.encrypt(sc, gpk, sd) for sc, sd in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def work(idx):
+        try:
+            for i in range(idx, len(jobs), 6):
+                got[i] = P.encrypt(jobs[i][0], gpk, jobs[i][1])
+        except Exception as e:          # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs
+    for a, b in zip(got, want):
+        assert np.array_equal(a.c1, b.c1) and np.array_equal(a.c2, b.c2)
+    sk = P.SecretKey.random(p, SEED, 0)
+    assert P.decrypt_party_shares(want[:n], sk, 0) == P.decrypt_party_shares(got[:n], sk, 0) if len(want) >= n else True
+
+
 def test_sharded_contexts_match_unsharded():
     # one process per GPU holds rows [party_lo, party_hi) of B and [c1_lo, c1_hi) of A
     n, k, l, moduli = 21, 12, 8, M.bench_moduli(3)
