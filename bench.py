@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--dealers", type=int, default=0,
                     help="encrypt path only: > 0 batches this many dealers per step through pvw_encrypt_multi "
                          "(encrypt_all_party_shares); value is then party-ciphertexts/s")
-    ap.add_argument("--path", default="encrypt", choices=["encrypt", "decrypt"],
+    ap.add_argument("--path", default="encrypt", choices=["encrypt", "decrypt", "keygen"],
                     help="encrypt = the headline metric; decrypt = batched decrypt_party_value (BASELINE configs[4] shape)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -98,6 +98,8 @@ def main():
 
     if args.path == "decrypt":
         return bench_decrypt(args, world, rank, local_rank, dev)
+    if args.path == "keygen":
+        return bench_keygen(args, world, rank, local_rank, dev)
     n_per, k, l, L, desc = CONFIGS[args.config or "c3"]
     n_total = n_per * world
     moduli = M.bench_moduli(L)
@@ -179,13 +181,14 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    kt = {name: params.kernel_time(name) for name in ("mac_rows", "mac_rows_multi", "prologue")}
+    kt = {name: params.kernel_time(name) for name in ("mac_rows", "mac_rows_multi", "gemm_digits", "vec_digits", "prologue")}
     params.set_profiling(False)
-    mac_ms, mac_launches = kt["mac_rows_multi"] if Dm > 0 else kt["mac_rows"]
+    gemm_path = Dm > 0 and kt["gemm_digits"][1] > 0
+    mac_ms, mac_launches = kt["gemm_digits"] if gemm_path else (kt["mac_rows_multi"] if Dm > 0 else kt["mac_rows"])
     mac_avg_s = mac_ms / max(mac_launches, 1) * 1e-3
     rows_a = chi - clo
     # algorithmic bytes of one mac_rows launch: B-hat + A-hat reads, c2 + c1 writes, r-hat read
-    nv = min(Dm, 4) if Dm > 0 else 1          # vectors sharing one pass over the matrix
+    nv = (min(Dm, 16) if gemm_path else min(Dm, 4)) if Dm > 0 else 1   # vectors sharing one pass over the matrix
     alg_bytes = 8 * L * l * (n_per * k + rows_a * k + nv * (n_per + rows_a + k))
     achieved = alg_bytes / mac_avg_s / 1e9 if mac_avg_s > 0 else 0.0
 
@@ -206,9 +209,10 @@ def main():
         "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},
     }
     if Dm > 0:
-        out["metric"] = "party-ciphertexts/s for encrypt_all_party_shares (D dealers x n parties, 4 dealers per pass over B-hat)"
+        out["metric"] = ("party-ciphertexts/s for encrypt_all_party_shares (D dealers x n parties, "
+                         + ("16" if gemm_path else "4") + " dealers per pass over B-hat)")
         out["unit"] = "party-ciphertexts/s"
-        out["roofline"]["kernel"] = "mac_rows_multi_kernel"
+        out["roofline"]["kernel"] = "gemm_digits_kernel (i8 MFMA)" if gemm_path else "mac_rows_multi_kernel"
         out["roofline"]["modular_macs_per_s"] = L * l * (n_per * k + rows_a * k) * nv / mac_avg_s if mac_avg_s > 0 else 0.0
 
     # ---- CPU baseline: the C restatement (oracle/) on this box's host cores, rank 0, N=1 only ----
@@ -261,6 +265,55 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def bench_keygen(args, world, rank, local_rank, dev):
+    """Batched key generation b_i = s_i*A + e_i (public_key.rs:111-147, crs.rs:138-171) for the parties
+    of this rank: 16 parties per pass over the transposed CRS on the matrix cores (gemm_digits)."""
+    import numpy as np
+    import torch  # noqa: F401
+
+    import pvw_model as M
+    import pvw_rs_amd as P
+    from pvw_rs_amd import _ffi
+
+    n_per, k, l, L, desc = CONFIGS[args.config or "c3"]
+    moduli = M.bench_moduli(L)
+    from pvw_rs_amd import dist as D
+    lo, hi, _, _ = D.shard_ranges(n_per * world, k, world, rank)
+    params = (P.PvwParametersBuilder().set_parties(n_per * world).set_dimension(k).set_l(l).set_moduli(moduli)
+              .set_device(local_rank).set_shard(lo, hi, 0, k).build())
+    h, lib = params._h, _ffi.lib()
+    P.PvwCrs.new_deterministic(params, SEED_A)
+    sk = np.zeros((n_per, k, l), dtype=np.int64)
+    P.api._check(lib.pvw_sample_secret_keys(h, np.frombuffer(SEED_ENC, dtype=np.uint8).ctypes.data_as(C.c_void_p),
+                                            lo, n_per, sk.ctypes.data_as(C.c_void_p)))
+    seed = np.frombuffer(SEED_B, dtype=np.uint8).copy()
+
+    def step():
+        P.api._check(lib.pvw_keygen(h, lo, hi, sk.ctypes.data_as(C.c_void_p), None, seed.ctypes.data_as(C.c_void_p)))
+
+    steps = max(1, min(args.steps, 5))
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    macs = L * l * n_per * k * k
+    out = {
+        "metric": "party public keys/s for batched PublicKey::generate (b_i = s_i*A + e_i), host sk in, B-hat resident out",
+        "value": n_per * world * steps / elapsed, "unit": "keys/s", "n_gpus": world, "steps": steps, "warmup": 1,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "key generation at " + desc, "parties_per_gpu": n_per, "k": k, "l": l, "rns_limbs": L},
+        "roofline": {"bound": "mfma", "kernel": "gemm_digits_kernel (i8 MFMA, 64 byte-products per modular MAC)",
+                     "achieved": macs * 64 * 2 / (elapsed / steps) / 1e12, "peak": 5000.0, "unit": "TOP/s (i8)",
+                     "frac": macs * 64 * 2 / (elapsed / steps) / 1e12 / 5000.0, "traffic": None,
+                     "modular_macs_per_s": macs / (elapsed / steps),
+                     "note": "whole pvw_keygen call incl. H2D of the secret keys, prologues and re-tiling of B-hat"},
+    }
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def bench_decrypt(args, world, rank, local_rank, dev):

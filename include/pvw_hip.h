@@ -233,6 +233,10 @@ PVW_API int32_t pvw_decode_device(pvw_ctx* ctx, const uint64_t* d_noisy, size_t 
 PVW_API int32_t pvw_selftest_decode_fixed(const pvw_ctx* ctx, const uint64_t* noisy, size_t count,
                                           uint64_t* out_u64);
 
+/* SELF-TEST: C[32][32] (int32) = A[32][32] * B[32][32] (int8, row-major) with one i8 MFMA fetched
+ * through the lane maps the digit-GEMM kernels assume. */
+PVW_API int32_t pvw_selftest_mfma_i8(pvw_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* out);
+
 /* ---- ring primitives (fhe-math call sites) -----------------------
  * change_representation(Ntt / PowerBasis) on `count` polynomials, host buffers, in place */
 PVW_API int32_t pvw_ntt_forward(pvw_ctx* ctx, uint64_t* polys, size_t count);

@@ -119,6 +119,13 @@ struct Workspace {
   u64* c2 = nullptr;         // [rowsB][L][l]
   void* scratch = nullptr;   // growable staging
   size_t scratch_bytes = 0;
+  // digit-GEMM operands for up to 16 vectors (allocated on first use)
+  u64* vhat16 = nullptr;     // [16][L][k][l]
+  signed char* yd = nullptr; // vector digit tiles
+  int* sy = nullptr;         // their column sums
+  u64* gtmpA = nullptr;      // GEMM intermediates [limb][slot][v][row]
+  u64* gtmpB = nullptr;
+  u64* gtmpK = nullptr;      // ... for key generation (k rows)
 };
 
 struct pvw_ctx {
@@ -146,6 +153,11 @@ struct pvw_ctx {
   DevTables dt{};
   u64* dA = nullptr;  // tiled A-hat rows [c1_lo, c1_hi)
   u64* dB = nullptr;  // tiled B-hat rows [party_lo, party_hi)
+  // MFMA-tiled copies for the digit GEMM (built lazily by the first many-dealer encrypt, dropped
+  // whenever A or B changes)
+  u64* xmA = nullptr;
+  u64* xmB = nullptr;
+  bool xm_valid = false;
   bool crs_loaded = false;
   u32 num_keys = 0;
   hipStream_t stream = nullptr;
@@ -387,6 +399,12 @@ static void ws_free(Workspace* w) {
   hipFree(w->c1);
   hipFree(w->c2);
   hipFree(w->scratch);
+  hipFree(w->vhat16);
+  hipFree(w->yd);
+  hipFree(w->sy);
+  hipFree(w->gtmpA);
+  hipFree(w->gtmpB);
+  hipFree(w->gtmpK);
   if (w->own_stream && w->stream) hipStreamDestroy(w->stream);
   delete w;
 }
@@ -531,6 +549,8 @@ int32_t pvw_ctx_destroy(pvw_ctx* c) {
     for (auto& kv : c->async_ws) ws_free(kv.second);
     hipFree(c->dA);
     hipFree(c->dB);
+    hipFree(c->xmA);
+    hipFree(c->xmB);
     hipFree(c->d_tables);
     hipFree(c->d_dec);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -713,6 +733,32 @@ static int32_t load_rows_host(pvw_ctx* c, u64* M, u32 shard_lo, u32 shard_hi, u3
   ws_release(c, w);
   return rc;
 }
+static int32_t ws_gemm_buffers(pvw_ctx* c, Workspace* w) {
+  if (!w->vhat16) PVW_HIP(hipMalloc((void**)&w->vhat16, (size_t)16 * c->k * c->poly() * 8));
+  if (!w->yd) PVW_HIP(hipMalloc((void**)&w->yd, yd_bytes(16, c->k, c->L, c->l)));
+  if (!w->sy) PVW_HIP(hipMalloc((void**)&w->sy, sy_bytes(16, c->L, c->l)));
+  if (!w->gtmpA && c->rowsA()) PVW_HIP(hipMalloc((void**)&w->gtmpA, gemm_tmp_words(c->rowsA(), c->L, c->l) * 8));
+  if (!w->gtmpB && c->rowsB()) PVW_HIP(hipMalloc((void**)&w->gtmpB, gemm_tmp_words(c->rowsB(), c->L, c->l) * 8));
+  return PVW_OK;
+}
+// MFMA-tiled copies of the resident A-hat / B-hat sections
+static int32_t ensure_xm(pvw_ctx* c, hipStream_t s) {
+  std::lock_guard<std::mutex> g(c->init_mu);
+  if (c->xm_valid) return PVW_OK;
+  const u32 rA = c->rowsA(), rB = c->rowsB();
+  const size_t wa = xm_words(rA, c->k, c->L, c->l), wb = xm_words(rB, c->k, c->L, c->l);
+  if (!c->xmA && wa) PVW_HIP(hipMalloc((void**)&c->xmA, wa * 8));
+  if (!c->xmB && wb) PVW_HIP(hipMalloc((void**)&c->xmB, wb * 8));
+  if (wa) PVW_HIP(hipMemsetAsync(c->xmA, 0, wa * 8, s));
+  if (wb) PVW_HIP(hipMemsetAsync(c->xmB, 0, wb * 8, s));
+  ProfScope ps(c, "mftile", s);
+  PVW_HIP(launch_mftile(c->dA, true, c->xmA, rA, c->k, c->L, c->l, s));
+  PVW_HIP(launch_mftile(c->dB, true, c->xmB, rB, c->k, c->L, c->l, s));
+  PVW_HIP(hipStreamSynchronize(s));
+  c->xm_valid = true;
+  return PVW_OK;
+}
+
 static int32_t check_repr(uint32_t repr) {
   if (repr != PVW_REPR_POWER && repr != PVW_REPR_NTT) return fail(PVW_ERR_INVALID_FORMAT, "unknown representation");
   return PVW_OK;
@@ -722,6 +768,7 @@ int32_t pvw_load_crs(pvw_ctx* c, const uint64_t* a, uint32_t repr) {
   if (!c || !a) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(check_repr(repr));
   PVW_TRY(ensure_device(c));
+  c->xm_valid = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   PVW_TRY(load_rows_host(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, a, repr));
   c->crs_loaded = true;
@@ -731,6 +778,7 @@ int32_t pvw_load_crs_device(pvw_ctx* c, const uint64_t* d_a, uint32_t repr, void
   if (!c || !d_a) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(check_repr(repr));
   PVW_TRY(ensure_device(c));
+  c->xm_valid = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   PVW_TRY(load_rows_device(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, d_a, repr, s));
@@ -740,6 +788,7 @@ int32_t pvw_load_crs_device(pvw_ctx* c, const uint64_t* d_a, uint32_t repr, void
 int32_t pvw_crs_generate(pvw_ctx* c, const uint8_t seed[32]) {
   if (!c || !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(ensure_device(c));
+  c->xm_valid = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   {
     ProfScope ps(c, "fill_uniform", c->stream);
@@ -794,6 +843,7 @@ int32_t pvw_load_pk(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t* b, uin
   PVW_TRY(check_repr(repr));
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
+  c->xm_valid = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   PVW_TRY(load_rows_host(c, c->dB, c->party_lo, c->party_hi, lo, hi, b, repr));
   if (hi > c->num_keys) c->num_keys = hi;                                          // public_key.rs:245-247
@@ -804,6 +854,7 @@ int32_t pvw_load_pk_device(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t*
   PVW_TRY(check_repr(repr));
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
+  c->xm_valid = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   PVW_TRY(load_rows_device(c, c->dB, c->party_lo, c->party_hi, lo, hi, d_b, repr, s));
@@ -813,6 +864,7 @@ int32_t pvw_load_pk_device(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t*
 int32_t pvw_pk_fill_uniform(pvw_ctx* c, const uint8_t seed[32]) {
   if (!c || !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(ensure_device(c));
+  c->xm_valid = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   {
     ProfScope ps(c, "fill_uniform", c->stream);
@@ -1145,27 +1197,46 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
                                      size_t D, u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
   const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
   const size_t P = c->poly();
-  for (size_t d0 = 0; d0 < D; d0 += 4) {
-    const u32 nv = (u32)((D - d0) < 4 ? (D - d0) : 4);
-    PrologueBatch pb{};
-    for (u32 v = 0; v < nv; ++v) {
-      pvw_randomness_t rnd{};
-      rnd.mode = PVW_RND_SEED;
-      memcpy(rnd.seed, seeds + (d0 + v) * 32, 32);
-      PVW_TRY(fill_encrypt_jobs(c, pb, v, 0, &rnd, d_scalars + (d0 + v) * c->n, w->rhat + (size_t)v * k * P,
-                                d_c1 + (d0 + v) * rA * P, d_c2 + (d0 + v) * rB * P));
-    }
-    pb.njobs = 3 * nv;
-    {
+  static int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 8; }();
+  const bool use_gemm = gemm_min > 0 && D >= (size_t)gemm_min;
+  if (use_gemm) {
+    PVW_TRY(ws_gemm_buffers(c, w));
+    PVW_TRY(ensure_xm(c, s));
+  }
+  const size_t group = use_gemm ? 16 : 4;
+  u64* vh = use_gemm ? w->vhat16 : w->rhat;
+  for (size_t d0 = 0; d0 < D; d0 += group) {
+    const u32 nv = (u32)((D - d0) < group ? (D - d0) : group);
+    // prologues, up to eight dealers per launch: r-hat_d -> vh[v], NTT(e1), NTT(e2) + m*g-hat -> output planes
+    for (u32 v0 = 0; v0 < nv; v0 += 8) {
+      const u32 cnt = (nv - v0) < 8 ? (nv - v0) : 8;
+      PrologueBatch pb{};
+      for (u32 x = 0; x < cnt; ++x) {
+        const size_t d = d0 + v0 + x;
+        pvw_randomness_t rnd{};
+        rnd.mode = PVW_RND_SEED;
+        memcpy(rnd.seed, seeds + d * 32, 32);
+        PVW_TRY(fill_encrypt_jobs(c, pb, x, 0, &rnd, d_scalars + d * c->n, vh + (size_t)(v0 + x) * k * P,
+                                  d_c1 + d * rA * P, d_c2 + d * rB * P));
+      }
+      pb.njobs = 3 * cnt;
       ProfScope ps(c, "prologue", s);
       PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
     }
-    {
+    u64* c1g = d_c1 + d0 * rA * P;
+    u64* c2g = d_c2 + d0 * rB * P;
+    if (use_gemm) {
+      {
+        ProfScope ps(c, "vec_digits", s);
+        PVW_HIP(launch_vec_digits(vh, (size_t)k * P, w->yd, w->sy, nv, k, L, l, c->dt, s));
+      }
+      ProfScope ps(c, "gemm_digits", s);
+      GemmSection a{c->xmA, c1g, c1g, w->gtmpA, rA, 0}, b{c->xmB, c2g, c2g, w->gtmpB, rB, 0};
+      PVW_HIP(launch_gemm_digits(a, b, w->yd, w->sy, c->dt, k, L, l, nv, (size_t)rA * P, (size_t)rB * P, s));
+    } else {
       ProfScope ps(c, "mac_rows_multi", s);
-      u64* c1g = d_c1 + d0 * rA * P;
-      u64* c2g = d_c2 + d0 * rB * P;
       MacSection a{c->dA, c1g, c1g, rA, 0}, b{c->dB, c2g, c2g, rB, 0};
-      MultiVec mv{w->rhat, (size_t)k * P, (size_t)rA * P, (size_t)rB * P, nv};
+      MultiVec mv{vh, (size_t)k * P, (size_t)rA * P, (size_t)rB * P, nv};
       PVW_HIP(launch_mac_rows_multi(a, b, mv, c->dt, k, L, l, s));
     }
   }
@@ -1313,6 +1384,26 @@ int32_t pvw_decode_host(const pvw_ctx* c, const uint64_t* noisy, size_t count, u
   return PVW_OK;
 }
 
+// SELF-TEST: one i8 MFMA through the operand maps the digit-GEMM kernels assume (exact integer data)
+int32_t pvw_selftest_mfma_i8(pvw_ctx* c, const int8_t* a, const int8_t* b, int32_t* out) {
+  if (!c || !a || !b || !out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(ensure_device(c));
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  int32_t rc = ws_scratch(w, 8192);
+  if (rc == PVW_OK) {
+    char* base = (char*)w->scratch;
+    if (hipMemcpyAsync(base, a, 1024, hipMemcpyHostToDevice, w->stream) != hipSuccess ||
+        hipMemcpyAsync(base + 1024, b, 1024, hipMemcpyHostToDevice, w->stream) != hipSuccess ||
+        launch_mfma_probe((const signed char*)base, (const signed char*)base + 1024, (int*)(base + 2048), w->stream) != hipSuccess ||
+        hipMemcpyAsync(out, base + 2048, 4096, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+        hipStreamSynchronize(w->stream) != hipSuccess)
+      rc = fail(PVW_ERR_INTERNAL, "mfma probe failed");
+  }
+  ws_release(c, w);
+  return rc;
+}
+
 // host execution of the fixed-width decode that the GPU runs (pvw_decode.h) -- a SELF-TEST hook so
 // the device algorithm can be checked on a machine without a GPU; not used by any product path.
 int32_t pvw_selftest_decode_fixed(const pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* out) {
@@ -1455,6 +1546,7 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   if (!ek && !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "either explicit key errors or a seed is required");
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
+  c->xm_valid = false;
   if (!c->crs_loaded) return fail(PVW_ERR_CRS, "CRS not loaded");
   if (c->rowsA() != c->k) return fail(PVW_ERR_KEY_GENERATION, "key generation needs the full CRS on this context");
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
@@ -1464,12 +1556,19 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   Workspace* w;
   PVW_TRY(ws_acquire(c, &w));
   hipStream_t s = w->stream;
-  // scratch: A in API layout [k][k][P] | A^T tiled | per-party: sk,ek small [2k][l], b row [k][P]
+  // >= 8 parties: 16 parties per pass on the matrix cores (gemm_digits); fewer: 4 per pass on the VALU
+  static int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 8; }();
+  const bool use_gemm = gemm_min > 0 && (b - a) >= (u32)gemm_min;
+  const u32 group = use_gemm ? 16 : 4;
+  // scratch: A in API layout [k][k][P] | A^T in API layout | A^T tiled or MFMA-tiled | sk,ek of one group | rows of B
   const size_t b_api = ((size_t)k * k * P * 8 + 255) & ~(size_t)255;
-  const size_t b_tt = (c->tiled_words(k) * 8 + 255) & ~(size_t)255;
-  const size_t b_small = ((size_t)8 * k * l * 8 + 255) & ~(size_t)255;   // sk + ek of 4 parties
-  const size_t b_row = ((size_t)4 * k * P * 8 + 255) & ~(size_t)255;      // 4 rows of B
-  int32_t rc = ws_scratch(w, 2 * b_api + b_tt + b_small + b_row);
+  const size_t b_tt = ((use_gemm ? xm_words(k, k, L, l) : c->tiled_words(k)) * 8 + 255) & ~(size_t)255;
+  const u32 chunk = (b - a) < 1024 ? (b - a) : 1024;   // parties whose sk / ek are uploaded together
+  const size_t b_small = ((size_t)2 * chunk * k * l * 8 + 255) & ~(size_t)255;
+  const size_t b_row = ((size_t)group * k * P * 8 + 255) & ~(size_t)255;
+  const size_t b_tmp = use_gemm ? ((gemm_tmp_words(k, L, l) * 8 + 255) & ~(size_t)255) : 0;
+  int32_t rc = ws_scratch(w, 2 * b_api + b_tt + b_small + b_row + b_tmp);
+  if (rc == PVW_OK && use_gemm) rc = ws_gemm_buffers(c, w);
   if (rc == PVW_OK) {
     char* base = (char*)w->scratch;
     u64* d_api = (u64*)base;
@@ -1477,40 +1576,57 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
     u64* d_tt = (u64*)(base + 2 * b_api);
     i64* d_small = (i64*)(base + 2 * b_api + b_tt);
     u64* d_row = (u64*)(base + 2 * b_api + b_tt + b_small);
-    // A -> API layout -> transpose polynomials (A^T[c][j] = A[j][c]) -> tiled
+    u64* d_tmp = (u64*)(base + 2 * b_api + b_tt + b_small + b_row);
+    u64* vh = use_gemm ? w->vhat16 : w->rhat;
+    // A -> API layout -> transpose polynomials (A^T[c][j] = A[j][c]) -> tiled / MFMA-tiled
     bool okk = launch_untile(c->dA, d_api, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
     for (u32 j = 0; okk && j < k; ++j)
       okk = hipMemcpy2DAsync(d_apiT + (size_t)j * P, (size_t)k * P * 8, d_api + (size_t)j * k * P, P * 8, P * 8, k,
                              hipMemcpyDeviceToDevice, s) == hipSuccess;
-    okk = okk && hipMemsetAsync(d_tt, 0, c->tiled_words(k) * 8, s) == hipSuccess;
-    okk = okk && launch_tile(d_apiT, d_tt, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
+    okk = okk && hipMemsetAsync(d_tt, 0, b_tt, s) == hipSuccess;
+    if (use_gemm) okk = okk && launch_mftile(d_apiT, false, d_tt, k, k, L, l, s) == hipSuccess;
+    else okk = okk && launch_tile(d_apiT, d_tt, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
     if (!okk) rc = fail(PVW_ERR_INTERNAL, "CRS transpose failed");
-    // groups of 4 parties share one pass over the transposed CRS (mac_rows_multi)
-    for (u32 p0 = a; rc == PVW_OK && p0 < b; p0 += 4) {
-      const u32 nv = (b - p0) < 4 ? (b - p0) : 4;
-      const size_t words = (size_t)nv * k * l;
-      if (hipMemcpyAsync(d_small, sk + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
-          (ek && hipMemcpyAsync(d_small + (size_t)4 * k * l, ek + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s) != hipSuccess)) {
-        rc = fail(PVW_ERR_INTERNAL, "H2D failed");
-        break;
+    for (u32 p0 = a; rc == PVW_OK && p0 < b; p0 += group) {
+      const u32 nv = (b - p0) < group ? (b - p0) : group;
+      const u32 in_chunk = (p0 - a) % chunk;                       // position inside the uploaded chunk
+      if (in_chunk == 0) {
+        const u32 cn = (b - p0) < chunk ? (b - p0) : chunk;
+        const size_t words = (size_t)cn * k * l;
+        if (hipMemcpyAsync(d_small, sk + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+            (ek && hipMemcpyAsync(d_small + (size_t)chunk * k * l, ek + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s) != hipSuccess)) {
+          rc = fail(PVW_ERR_INTERNAL, "H2D failed");
+          break;
+        }
       }
-      PrologueBatch pb{};
-      if (seed) pb.key[0] = make_key(seed);
-      for (u32 v = 0; v < nv; ++v) {
-        PrologueJob& js = pb.job[2 * v];
-        PrologueJob& je = pb.job[2 * v + 1];
-        js.sj.count = k; js.explicit_coeffs = d_small + (size_t)v * k * l;                 // secret_key.rs:98-112
-        js.out = w->rhat + (size_t)v * k * P; js.stride_poly = l; js.stride_limb = (size_t)k * l;
-        je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = (p0 + v) * k; je.sj.count = k; je.sj.bound = c->b1;  // public_key.rs:128-132
-        if (ek) je.explicit_coeffs = d_small + (size_t)(4 + v) * k * l;
-        je.out = d_row + (size_t)v * k * P; je.stride_poly = P; je.stride_limb = l;
-      }
-      pb.njobs = 2 * nv;
       ProfScope ps(c, "keygen", s);
-      bool ok2 = launch_prologue(pb, c->dt, L, l, s) == hipSuccess;
-      MacSection sa{d_tt, d_row, d_row, k, 0}, sb{nullptr, nullptr, nullptr, 0, 0};
-      MultiVec mv{w->rhat, (size_t)k * P, (size_t)k * P, 0, nv};
-      ok2 = ok2 && launch_mac_rows_multi(sa, sb, mv, c->dt, k, L, l, s) == hipSuccess;                   // crs.rs:152-168
+      bool ok2 = true;
+      for (u32 v0 = 0; ok2 && v0 < nv; v0 += 16) {                 // s-hat_p and NTT(e_p), up to 16 parties per launch
+        const u32 cnt = (nv - v0) < 16 ? (nv - v0) : 16;
+        PrologueBatch pb{};
+        if (seed) pb.key[0] = make_key(seed);
+        for (u32 x = 0; x < cnt; ++x) {
+          const u32 v = v0 + x;
+          PrologueJob& js = pb.job[2 * x];
+          PrologueJob& je = pb.job[2 * x + 1];
+          js.sj.count = k; js.explicit_coeffs = d_small + (size_t)(in_chunk + v) * k * l;    // secret_key.rs:98-112
+          js.out = vh + (size_t)v * k * P; js.stride_poly = l; js.stride_limb = (size_t)k * l;
+          je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = (p0 + v) * k; je.sj.count = k; je.sj.bound = c->b1;  // public_key.rs:128-132
+          if (ek) je.explicit_coeffs = d_small + (size_t)(chunk + in_chunk + v) * k * l;
+          je.out = d_row + (size_t)v * k * P; je.stride_poly = P; je.stride_limb = l;
+        }
+        pb.njobs = 2 * cnt;
+        ok2 = launch_prologue(pb, c->dt, L, l, s) == hipSuccess;
+      }
+      if (use_gemm) {                                                                        // crs.rs:152-168
+        ok2 = ok2 && launch_vec_digits(vh, (size_t)k * P, w->yd, w->sy, nv, k, L, l, c->dt, s) == hipSuccess;
+        GemmSection ga{d_tt, d_row, d_row, d_tmp, k, 0}, gb{nullptr, nullptr, nullptr, nullptr, 0, 0};
+        ok2 = ok2 && launch_gemm_digits(ga, gb, w->yd, w->sy, c->dt, k, L, l, nv, (size_t)k * P, 0, s) == hipSuccess;
+      } else {
+        MacSection sa{d_tt, d_row, d_row, k, 0}, sb{nullptr, nullptr, nullptr, 0, 0};
+        MultiVec mv{vh, (size_t)k * P, (size_t)k * P, 0, nv};
+        ok2 = ok2 && launch_mac_rows_multi(sa, sb, mv, c->dt, k, L, l, s) == hipSuccess;
+      }
       // d_row is [nv][k polys][P] = nv rows of B in API layout -> tile into B
       ok2 = ok2 && launch_tile(d_row, c->dB, nv, p0 - c->party_lo, k, L, l, false, c->dt, s) == hipSuccess;
       if (!ok2) rc = fail(PVW_ERR_KEY_GENERATION, "keygen launch failed");

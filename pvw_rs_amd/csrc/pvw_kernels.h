@@ -73,10 +73,11 @@ struct PrologueJob {
   size_t stride_poly, stride_limb;
   u32 key_idx;   // which key of the batch seeds this family
 };
-#define PVW_MAX_PROLOGUE_JOBS 12
-#define PVW_MAX_PROLOGUE_KEYS 4
-// up to 4 encrypts' worth of polynomial families (r, e1, e2 each) in one launch
-struct PrologueBatch {
+#define PVW_MAX_PROLOGUE_JOBS 32
+#define PVW_MAX_PROLOGUE_KEYS 16
+// up to 10 encrypts' (r, e1, e2) or 16 key generations' (s, e) worth of polynomial families in one
+// launch; the whole batch travels in the kernel-argument segment (< 4 KiB)
+struct PrologueBatch {   // sizeof must stay below the 4 KiB kernel-argument limit
   PrologueJob job[PVW_MAX_PROLOGUE_JOBS];
   ChaChaKey key[PVW_MAX_PROLOGUE_KEYS];
   u32 njobs;
@@ -103,6 +104,35 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
                               const DevTables& t, u32 k, u32 L, u32 ell, size_t dealers,
                               hipStream_t s);
 
+// ---- digit GEMM on the matrix cores (see pvw_kernels.hip) ----
+#define PVW_GEMM_RPW 1                                   // row tiles (of 32 rows) per wave
+#define PVW_GEMM_ROWS_PER_WG (4 * PVW_GEMM_RPW * 32)     // 4 waves per workgroup
+// XM = MFMA-tiled copy of a matrix section: [limb][slot][row tile of 32][j block of 4][64 lanes][2 u64],
+// row tiles padded to whole workgroups (4 waves x PVW_GEMM_RPW row tiles).
+struct GemmSection {
+  const u64* XM;
+  const u64* addend;   // per-vector planes, same indexing as out (may alias out; NULL = none)
+  u64* out;
+  u64* tmp;            // intermediate [limb][slot][16 vectors][rows padded to whole workgroups]
+  u32 nrows;
+  u32 rt_groups;       // filled in by the launcher
+};
+inline size_t gemm_tmp_words(u32 rows, u32 L, u32 ell) {
+  return (size_t)L * ell * 16 * (((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * PVW_GEMM_ROWS_PER_WG);
+}
+inline size_t xm_words(u32 rows, u32 k, u32 L, u32 ell) {
+  return (size_t)L * ell * (((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * (PVW_GEMM_ROWS_PER_WG / 32)) *
+         ((k + 3) / 4) * 128;
+}
+inline size_t yd_bytes(u32 nv, u32 k, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) * L * ell * ((k + 3) / 4) * 1024; }
+inline size_t sy_bytes(u32 nv, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) * L * ell * 32 * sizeof(int); }
+hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s);
+hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
+                             const DevTables& t, hipStream_t s);
+hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
+                              const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
+                              hipStream_t s);
+hipError_t launch_mfma_probe(const signed char* A, const signed char* B, int* C, hipStream_t s);
 hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s);
 
 }  // namespace pvw

@@ -1098,6 +1098,304 @@ __global__ __launch_bounds__(256) void decode_wave_kernel(const u64* __restrict_
 }
 
 // ------------------------------------------------------------------------------------
+// i8 MFMA operand-map probe (self-test): C[32][32] = A[32][32] * B[32][32] with ONE
+// v_mfma_i32_32x32x32_i8, operands fetched with the lane maps the digit-GEMM kernels rely on:
+//   A fragment of lane l (r = l & 31, h = l >> 5): A[r][16h .. 16h+15]     (16 consecutive K)
+//   B fragment:                                   B[16h .. 16h+15][r]
+//   C/D register g of lane l:                      C[(g & 3) + 8 (g >> 2) + 4 h][r]
+// ------------------------------------------------------------------------------------
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64) void mfma_i8_probe_kernel(const signed char* __restrict__ A,
+                                                            const signed char* __restrict__ B, int* __restrict__ Cm) {
+  const u32 l = threadIdx.x, r = l & 31, h = l >> 5;
+  union { v4i32 v; signed char b[16]; } fa, fb;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    fa.b[j] = A[r * 32 + 16 * h + j];
+    fb.b[j] = B[(16 * h + j) * 32 + r];
+  }
+  v16i32 acc = {};
+  acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa.v, fb.v, acc, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 16; ++g) Cm[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r] = acc[g];
+}
+
+// ====================================================================================
+// Digit GEMM on the matrix cores: NV (up to 16) vectors against one pass over the matrix.
+//
+// For many vectors the k-term inner products are a genuine GEMM per (limb, slot),
+//     out[row][v] = sum_j X[row][j] * Y[j][v]   (mod q),
+// and the integer VALU (4 v_mad_u64_u32 per MAC, ~1.6e12 MAC/s) is the bound.  On the matrix
+// cores a 64x64-bit modular product is folded into i8 MFMAs like this:
+//     x * y = sum_a x_a 2^(8a) * y  ==  sum_a x_a * y^(a)   (mod q),   y^(a) = 2^(8a) y mod q
+// so the sum over the 8 bytes x_a of x joins the contraction index: K = (j, a).  The A operand is
+// then the RAW little-endian u64 data (16 bytes per lane = 2 consecutive j of one row) and each
+// vector element contributes 8 shifted copies, written as 8 balanced base-256 digits
+// y^(a) = sum_b d_b 2^(8b), d_b in [-128, 127]:  B[(j,a)][(v,b)] = d_b(y_v^(a)[j]).
+// One v_mfma_i32_32x32x32_i8 = 32 rows x 4 vectors x 4 j = 512 modular MACs, and only 8 partial
+// sums per output remain to be recombined: out = sum_b C[row][(v,b)] 2^(8b) mod q.
+// The raw bytes are unsigned: they are offset by -128 (xor 0x80) and 128 * colsum(B) is added back.
+// Used by multi-dealer encrypt (>= 8 dealers) and batched key generation; the single-vector
+// encrypt stays on mac_rows (a GEMV: HBM-bound, no matrix-core shape).
+// ====================================================================================
+
+// tiled matrix (or API-layout rows) -> MFMA-tiled copy XM[limb][slot][rt][jb][h*32+m][2]
+template <int ELL>
+__global__ __launch_bounds__(256) void mftile_kernel(const u64* __restrict__ src, u32 src_is_tiled,
+                                                      u64* __restrict__ XM, u32 rows, u32 k, u32 L) {
+  constexpr int R = 128 / ELL;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (size_t)rows * k * L) return;
+  const u32 limb = tid % L;
+  const u32 j = (tid / L) % k;
+  const u32 row = tid / ((size_t)L * k);
+  const u64* p = src_is_tiled ? src + (((size_t)(row / R) * L + limb) * k + j) * 128 + (row % R) * ELL
+                              : src + tid * ELL;     // API layout [row][j][limb][slot]
+  const u32 RT = ((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * (PVW_GEMM_ROWS_PER_WG / 32), JB = (k + 3) / 4;   // row tiles padded to whole workgroups
+  const u32 rt = row >> 5, m = row & 31, jb = j >> 2, h = (j >> 1) & 1, e = j & 1;
+#pragma unroll
+  for (int sl = 0; sl < ELL; ++sl) {
+    const size_t tile = (((size_t)limb * ELL + sl) * RT + rt) * JB + jb;
+    XM[tile * 128 + (h * 32 + m) * 2 + e] = p[sl];
+  }
+}
+
+// vector elements -> digit tiles YD[vg][limb][slot][jb][h*32+col][16] and column sums SY.
+// One wave per (v, limb, slot); lane = j-block: each lane turns 4 consecutive j into the 8 shifted
+// copies y*2^(8a) mod q, writes their balanced digits as 16 16-byte runs, and the column sums are
+// reduced across the wave (no atomics).
+template <int ELL>
+__global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ vhat, size_t vstride,
+                                                         signed char* __restrict__ YD, int* __restrict__ SY,
+                                                         u32 nv, u32 k, u32 L, DevTables t) {
+  const u32 lane = threadIdx.x;
+  const u32 slot = blockIdx.x % ELL;
+  const u32 limb = (blockIdx.x / ELL) % L;
+  const u32 v = blockIdx.x / (ELL * L);
+  const Mod m = t.mods[limb];
+  const u32 JB = (k + 3) / 4;
+  const u32 vg = v >> 2, v4 = v & 3;
+  const u64 w256p = (m.ratio_hi << 8) | (m.ratio_lo >> 56);   // floor(256 * 2^64 / q) = floor(2^128 / q) >> 56
+  const u64* y = vhat + (size_t)v * vstride + (size_t)limb * k * ELL + slot;
+  signed char* tiles = YD + (((size_t)vg * L + limb) * ELL + slot) * (size_t)JB * 1024;
+  int colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (u32 jb = lane; jb < JB; jb += 64) {
+    // digit[b][kappa], kappa = 8*jj + a  (32 bytes per digit column b)
+    union { signed char c[8][32]; v4i32 q[8][2]; } dg;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const u32 j = 4 * jb + jj;
+      u64 cur = j < k ? y[(size_t)j * ELL] : 0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        u64 w = cur;
+        int carry = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          int d = (int)(w & 0xff) + carry;
+          w >>= 8;
+          carry = d > 127;
+          d -= carry << 8;
+          dg.c[b][8 * jj + a] = (signed char)d;
+          colsum[b] += d;
+        }
+        cur = mulmod_shoup(cur, 256, w256p, m.q);
+      }
+    }
+    signed char* tile = tiles + (size_t)jb * 1024;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      *reinterpret_cast<v4i32*>(tile + (size_t)(0 * 32 + v4 * 8 + b) * 16) = dg.q[b][0];   // h = 0: kappa 0..15
+      *reinterpret_cast<v4i32*>(tile + (size_t)(1 * 32 + v4 * 8 + b) * 16) = dg.q[b][1];   // h = 1: kappa 16..31
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    int sum = colsum[b];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) SY[(((size_t)vg * L + limb) * ELL + slot) * 32 + v4 * 8 + b] = sum;
+  }
+}
+
+template <int ELL, int NVG, int RPW>
+__global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
+                                                           const int* __restrict__ SY, const Mod* __restrict__ mods,
+                                                           u32 k, u32 L, u32 nv, u32 nv_pad) {
+  // block = (limb, slot, group of 4*RPW row tiles); the 4 waves share the vector-digit tiles through
+  // LDS (CJ j-blocks at a time); each wave owns RPW row tiles of 32 rows and streams their raw u64 tiles.
+  constexpr int CJ = 8;                                    // j-blocks per staged chunk (32 MFMAs per wave per barrier)
+  constexpr int BSH = NVG * CJ * 64 / 256;                 // 16-byte B elements each thread stages per chunk
+  __shared__ v4i32 bl[2][NVG * CJ * 64];                   // two chunks of NVG*CJ KiB
+  const u32 JB = (k + 3) / 4;
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 rtg_total = sa.rt_groups + sb.rt_groups;
+  // XCD-aware order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of
+  // block ids -- workgroups that share the vector-digit tiles of one (limb, slot) then hit in L2
+  u32 bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const u32 ls = bid / rtg_total, rtg = bid % rtg_total;
+  const u32 limb = ls / ELL, slot = ls % ELL;
+  const bool in_a = rtg < sa.rt_groups;
+  const GemmSection& sec = in_a ? sa : sb;
+  const u32 rt0 = ((in_a ? rtg : rtg - sa.rt_groups) * 4 + wave) * RPW;
+  const u32 RT = sec.rt_groups * 4 * RPW;
+  const u32 rows_pad = sec.rt_groups * PVW_GEMM_ROWS_PER_WG;
+  const v4i32* ap[RPW];
+  bool live[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    ap[r] = reinterpret_cast<const v4i32*>(sec.XM) + ((((size_t)limb * ELL + slot) * RT + rt0 + r) * JB) * 64 + lane;
+    live[r] = ((rt0 + r) * 32) < sec.nrows;              // wave-uniform
+  }
+  const v4i32* ybase = reinterpret_cast<const v4i32*>(YD);
+  v16i32 acc[RPW][NVG];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int g = 0; g < NVG; ++g) acc[r][g] = (v16i32){};
+  const v4i32 flip = (v4i32){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+  const v4i32 zero4 = (v4i32){0, 0, 0, 0};
+  // software pipeline over chunks of CJ j-blocks: the A tiles and this thread's share of the B tiles
+  // of chunk c+1 are in flight (registers) while chunk c is multiplied out of LDS
+  auto fetch_a = [&](u32 jc, v4i32 (&an)[RPW][CJ]) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int u = 0; u < CJ; ++u)
+        an[r][u] = (live[r] && jc + u < JB) ? __builtin_nontemporal_load(ap[r] + (size_t)(jc + u) * 64) : flip;
+  };
+  auto fetch_b = [&](u32 jc, v4i32 (&bn)[BSH]) {
+#pragma unroll
+    for (int x = 0; x < BSH; ++x) {
+      const u32 e = threadIdx.x + 256 * x;                  // element of the [NVG][CJ][64] chunk
+      const u32 g = e / (CJ * 64), rem = e % (CJ * 64), u = rem / 64;
+      bn[x] = (jc + u < JB) ? ybase[((((size_t)g * L + limb) * ELL + slot) * JB + jc) * 64 + rem] : zero4;
+    }
+  };
+  // A tiles are prefetched TWO chunks ahead (register ring a -> an -> an2), B one chunk ahead (bn -> LDS)
+  v4i32 a[RPW][CJ], an[RPW][CJ], an2[RPW][CJ], bn[BSH];
+  fetch_b(0, bn);
+  fetch_a(0, a);
+  fetch_a(CJ, an);
+#pragma unroll
+  for (int x = 0; x < BSH; ++x) bl[0][threadIdx.x + 256 * x] = bn[x];
+  __syncthreads();
+  u32 cur = 0;
+  for (u32 jc = 0; jc < JB; jc += CJ) {
+    const bool more = jc + CJ < JB;
+    if (more) fetch_b(jc + CJ, bn);
+    fetch_a(jc + 2 * CJ, an2);                              // past the end: synthesised zero tiles, no memory access
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+#pragma unroll
+      for (int u = 0; u < CJ; ++u) {
+        const v4i32 ax = a[r][u] ^ flip;                    // tiles past the end were fetched as `flip`: zero bytes here
+#pragma unroll
+        for (int g = 0; g < NVG; ++g)
+          acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ax, bl[cur][g * (CJ * 64) + u * 64 + lane], acc[r][g], 0, 0, 0);
+      }
+    }
+    if (more) {
+      // the other buffer was last read in the previous iteration, which every wave left through the barrier below
+#pragma unroll
+      for (int x = 0; x < BSH; ++x) bl[cur ^ 1][threadIdx.x + 256 * x] = bn[x];
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int u = 0; u < CJ; ++u) { a[r][u] = an[r][u]; an[r][u] = an2[r][u]; }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // recombine: out[m][v] = sum_b (C[m][(v,b)] + 128*SY[(v,b)]) 2^(8b)  mod q.
+  // Lane (v, b) holds column b of 16 rows; an 8x8 transpose across the 8 lanes of a vector (three
+  // exchange steps on raw i32 values) gives lane b all eight digits of rows `b` and `b+8` of its
+  // register file, which it then weighs, reduces and stores.
+  const Mod m = mods[limb];
+  const u32 h = lane >> 5, col = lane & 31, b = col & 7, v4 = col >> 3;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    if (!live[r]) continue;
+#pragma unroll
+    for (int g = 0; g < NVG; ++g) {
+      const u32 v = g * 4 + v4;
+      const int sy128 = 128 * SY[(((size_t)g * L + limb) * ELL + slot) * 32 + col];
+      int x[16];
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) x[tt] = acc[r][g][tt] + sy128;          // |.| < 2^27
+#pragma unroll
+      for (int d = 1; d <= 4; d <<= 1) {
+        const bool up = (b & d) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if ((i & d) == 0) {
+            // lanes with bit d clear trade their register i|d for the partner's register i.
+            // (the empty asm pins both values in registers: without it hipcc folds the select into a
+            // runtime register index and expands every access into a 16-way v_cndmask chain)
+            int xi = x[i], xj = x[i | d];
+            asm("" : "+v"(xi));
+            asm("" : "+v"(xj));
+            const int send = up ? xi : xj;
+            const int recv = __shfl_xor(send, d);
+            x[i] = up ? recv : xi;
+            x[i | d] = up ? xj : recv;
+          }
+        }
+      }
+      // now x[i] (i < 8) = digit i of the row of original register b, x[8+i] = digit i of register b+8
+#pragma unroll
+      for (int z = 0; z < 2; ++z) {
+        const u32 tt = b + 8 * z;
+        const u32 row = (rt0 + r) * 32 + (tt & 3) + 8 * (tt >> 2) + 4 * h;
+        long long lo4 = 0, hi4 = 0;                                            // each < 2^27 * 2^24 * 4 < 2^53
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lo4 += (long long)x[8 * z + i] << (8 * i);
+          hi4 += (long long)x[8 * z + 4 + i] << (8 * i);
+        }
+        const __int128 tot = (__int128)lo4 + ((__int128)hi4 << 32);
+        if (row < sec.nrows && v < nv) {
+          u64 lo = (u64)tot, hi = (u64)((unsigned __int128)tot >> 64);
+          const bool neg = (long long)hi < 0;
+          if (neg) { lo = ~lo + 1; hi = ~hi + (lo == 0); }
+          u64 res = reduce128(lo, hi, m);
+          if (neg && res) res = m.q - res;
+          // intermediate [limb][slot][v][row]: the 16 lanes of one vector write 16 consecutive rows
+          sec.tmp[(((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res;
+        }
+      }
+    }
+  }
+}
+
+// gemm_finish: intermediate [limb][slot][v][row] -> API layout out[v][row][limb][slot] (+ addend),
+// 256-byte runs in, 8*l-byte runs out, through an LDS tile of 32 rows x l slots.
+template <int ELL>
+__global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const Mod* __restrict__ mods, u32 L,
+                                                           u32 nv, u32 nv_pad, u32 rows_pad, size_t ostride) {
+  __shared__ u64 tile[ELL][33];
+  const u32 rb = blockIdx.x, v = blockIdx.y, limb = blockIdx.z;
+  const u32 row0 = rb * 32;
+  for (u32 e = threadIdx.x; e < 32 * ELL; e += 256) {
+    const u32 row = e & 31, slot = e >> 5;
+    tile[slot][row] = sec.tmp[(((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row0 + row];
+  }
+  __syncthreads();
+  const u64 q = mods[limb].q;
+  for (u32 e = threadIdx.x; e < 32 * ELL; e += 256) {
+    const u32 slot = e % ELL, row = e / ELL;
+    if (row0 + row < sec.nrows) {
+      const size_t o = (size_t)v * ostride + ((size_t)(row0 + row) * L + limb) * ELL + slot;
+      u64 res = tile[slot][row];
+      if (sec.addend) res = addmod(res, sec.addend[o], q);
+      sec.out[o] = res;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
 #define PVW_DISPATCH_ELL(ell, ...)                       \
@@ -1317,6 +1615,63 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
   return hipGetLastError();
 }
 
+hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  const size_t threads = (size_t)rows * k * L;
+  PVW_DISPATCH_ELL(ell, mftile_kernel<E><<<dim3((u32)((threads + 255) / 256)), dim3(256), 0, s>>>(src, src_is_tiled ? 1u : 0u, XM, rows, k, L));
+  return hipGetLastError();
+}
+
+hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
+                             const DevTables& t, hipStream_t s) {
+  if (nv == 0) return hipSuccess;
+  // unused vector slots of the last group must read as zero digits / zero sums
+  if (nv % 4) {
+    const u32 NVG = (nv + 3) / 4, JB = (k + 3) / 4;
+    hipError_t e = hipMemsetAsync(YD + (size_t)(NVG - 1) * L * ell * JB * 1024, 0, (size_t)L * ell * JB * 1024, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(SY + (size_t)(NVG - 1) * L * ell * 32, 0, (size_t)L * ell * 32 * sizeof(int), s);
+    if (e != hipSuccess) return e;
+  }
+  PVW_DISPATCH_ELL(ell, vec_digits_kernel<E><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t));
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
+                              const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
+                              hipStream_t s) {
+  GemmSection sa = a, sb = b;
+  sa.rt_groups = (sa.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
+  sb.rt_groups = (sb.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
+  const u32 blocks = (sa.rt_groups + sb.rt_groups) * L * ell;
+  if (blocks == 0 || nv == 0) return hipSuccess;
+  const u32 NVG = (nv + 3) / 4;
+  const u32 nv_pad = NVG * 4;
+#define PVW_GEMM_LAUNCH(G) PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad))
+  switch (NVG) {
+    case 1: PVW_GEMM_LAUNCH(1); break;
+    case 2: PVW_GEMM_LAUNCH(2); break;
+    case 3: PVW_GEMM_LAUNCH(3); break;
+    case 4: PVW_GEMM_LAUNCH(4); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef PVW_GEMM_LAUNCH
+  if (sa.nrows) {
+    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sa.nrows + 31) / 32, nv, L), dim3(256), 0, s>>>(
+                              sa, t.mods, L, nv, nv_pad, sa.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_a));
+  }
+  if (sb.nrows) {
+    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sb.nrows + 31) / 32, nv, L), dim3(256), 0, s>>>(
+                              sb, t.mods, L, nv, nv_pad, sb.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_b));
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_mfma_probe(const signed char* A, const signed char* B, int* C, hipStream_t s) {
+  mfma_i8_probe_kernel<<<dim3(1), dim3(64), 0, s>>>(A, B, C);
+  return hipGetLastError();
+}
+
 hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s) {
   if (count == 0) return hipSuccess;
   const size_t lds = (size_t)(2 * t.W + 1 + t.L) * 64 * sizeof(u64);
@@ -1336,3 +1691,4 @@ hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeT
 }
 
 }  // namespace pvw
+static_assert(sizeof(pvw::PrologueBatch) <= 4000, "PrologueBatch must fit the kernel-argument segment");

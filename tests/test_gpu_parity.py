@@ -318,6 +318,30 @@ def test_multi_dealer_encrypt_equals_separate_encrypts(D):
         P.encrypt_many([[1, 2, 3]], gpk, seeds[:1])
 
 
+@pytest.mark.parametrize("n,k,l,L,D", [
+    (13, 9, 8, 4, 9),         # ragged: k not a multiple of 4, rows not a multiple of 32, one partial vector group
+    (70, 40, 8, 3, 16),       # more than two row tiles in the B section
+    (10, 6, 16, 3, 21),       # l = 16, two passes of 16 + 5 dealers
+    (5, 12, 32, 2, 8),        # l = 32
+    (200, 256, 8, 17, 8),     # config-3 geometry (k=256, 17 limbs) at a small party count
+])
+def test_digit_gemm_multi_dealer_equals_separate_encrypts(n, k, l, L, D):
+    # >= 8 dealers take the matrix-core path (gemm_digits_kernel): i8 MFMA over byte-folded operands
+    moduli = M.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    rng = np.random.default_rng(D)
+    rows = [[int(x) for x in rng.integers(0, 1 << 63, size=n, dtype=np.uint64)] for _ in range(D)]
+    rows[0][0] = (1 << 64) - 5
+    seeds = [P.api._dealer_seed(SEED, d) for d in range(D)]
+    many = P.encrypt_many(rows, gpk, seeds)
+    for d in range(D):
+        one = P.encrypt(rows[d], gpk, seeds[d])
+        assert np.array_equal(many[d].c1, one.c1), f"c1 dealer {d}"
+        assert np.array_equal(many[d].c2, one.c2), f"c2 dealer {d}"
+
+
 def test_multi_dealer_encrypt_l16_and_sharded():
     n, k, l, moduli = 10, 6, 16, TEST_MODULI
     full = build_params(n, k, l, moduli)
@@ -388,6 +412,20 @@ def test_concurrent_encrypt_calls_on_one_context():
         assert np.array_equal(a.c1, b.c1) and np.array_equal(a.c2, b.c2)
     sk = P.SecretKey.random(p, SEED, 0)
     assert P.decrypt_party_shares(want[:n], sk, 0) == P.decrypt_party_shares(got[:n], sk, 0) if len(want) >= n else True
+
+
+def test_mfma_i8_operand_maps():
+    # exact-integer check of the lane maps the digit-GEMM kernels rely on (asymmetric operands)
+    import ctypes as C
+    from pvw_rs_amd import _ffi
+    p = build_params(3, 4, 8, TEST_MODULI)
+    rng = np.random.default_rng(5)
+    a = rng.integers(-128, 128, size=(32, 32), dtype=np.int8)
+    b = rng.integers(-128, 128, size=(32, 32), dtype=np.int8)
+    out = np.zeros((32, 32), dtype=np.int32)
+    P.api._check(_ffi.lib().pvw_selftest_mfma_i8(p._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                                out.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(out, a.astype(np.int32) @ b.astype(np.int32))
 
 
 def test_sharded_contexts_match_unsharded():
