@@ -1219,6 +1219,15 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
   }
 }
 
+// value of lane (l ^ d), d in {1, 2, 4}, through DPP (no LDS crossbar): quad_perm for 1 and 2,
+// row_half_mirror (l ^ 7 within 8 lanes) followed by quad reversal (l ^ 3) for 4
+__device__ __forceinline__ int xor_lane_dpp(int v, int d) {
+  if (d == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  if (d == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  const int t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);        // row_half_mirror
+  return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, false);                // quad_perm [3,2,1,0]
+}
+
 template <int ELL, int NVG, int RPW>
 __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
                                                            const int* __restrict__ SY, const Mod* __restrict__ mods,
@@ -1274,7 +1283,8 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
       bn[x] = (jc + u < JB) ? ybase[((((size_t)g * L + limb) * ELL + slot) * JB + jc) * 64 + rem] : zero4;
     }
   };
-  // A tiles are prefetched TWO chunks ahead (register ring a -> an -> an2), B one chunk ahead (bn -> LDS)
+  // A tiles are prefetched TWO chunks ahead (register ring a -> an -> an2), B one chunk ahead (bn -> LDS).
+  // (A ring rotated by renaming -- the loop unrolled by three -- measured slower than these moves.)
   v4i32 a[RPW][CJ], an[RPW][CJ], an2[RPW][CJ], bn[BSH];
   fetch_b(0, bn);
   fetch_a(0, a);
@@ -1338,7 +1348,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
             asm("" : "+v"(xi));
             asm("" : "+v"(xj));
             const int send = up ? xi : xj;
-            const int recv = __shfl_xor(send, d);
+            const int recv = xor_lane_dpp(send, d);
             x[i] = up ? recv : xi;
             x[i | d] = up ? xj : recv;
           }
