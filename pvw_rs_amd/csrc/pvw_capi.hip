@@ -112,7 +112,6 @@ struct ProfRec {
 struct Workspace {
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  i64* small = nullptr;      // [(2k + nB)][l] sampled / uploaded small coefficients
   u64* rhat = nullptr;       // [L][k][l]
   u64* scalars = nullptr;    // [n]
   u64* c1 = nullptr;         // [rowsA][L][l]
@@ -370,8 +369,7 @@ static int32_t ensure_device(pvw_ctx* c) {
 }
 
 static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
-  const size_t l = c->l, k = c->k, P = c->poly();
-  PVW_HIP(hipMalloc((void**)&w->small, (2 * k + c->rowsB()) * l * sizeof(i64) + 16));
+  const size_t k = c->k, P = c->poly();
   PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
   return PVW_OK;
 }
@@ -393,7 +391,6 @@ static int32_t ws_scratch(Workspace* w, size_t bytes) {
 }
 static void ws_free(Workspace* w) {
   if (!w) return;
-  hipFree(w->small);
   hipFree(w->rhat);
   hipFree(w->scalars);
   hipFree(w->c1);

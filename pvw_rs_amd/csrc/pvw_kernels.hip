@@ -926,6 +926,8 @@ __device__ __forceinline__ void col_mac(u64& c0, u64& c1, u64& c2, u64 a, u64 b)
 
 struct WaveDecodeCtx {
   const DecodeTables& t;
+  const u64* qiL;    // LDS copy of t.qi    [L][W]
+  const u64* powL;   // LDS copy of t.pow64T [W][L]
   u64* xs;     // per-wave LDS scratch, 64 words
   u32 lane;
   u32 W, L;
@@ -956,7 +958,8 @@ __device__ __forceinline__ u64 wave_lift_centered(const WaveDecodeCtx& c, u64 re
   __builtin_amdgcn_wave_barrier();
   u64 c0 = 0, c1 = 0, c2 = 0;
   if (c.word_on) {
-    for (u32 i = 0; i < c.L; ++i) col_mac(c0, c1, c2, c.xs[i], t.qi[(size_t)i * c.W + lane]);
+#pragma unroll 4
+    for (u32 i = 0; i < c.L; ++i) col_mac(c0, c1, c2, c.xs[i], c.qiL[i * c.W + lane]);
   }
   __builtin_amdgcn_wave_barrier();
   u64 x = wave_normalize(c0, c1, c2, lane);
@@ -983,7 +986,7 @@ __device__ __forceinline__ u64 wave_to_rns(const WaveDecodeCtx& c, u64 x, bool n
   if (c.limb_on) {
     Acc acc;
     acc_zero(acc);
-    for (u32 j = 0; j < c.W; ++j) acc_mac_dev(acc, c.xs[j], c.t.pow64T[(size_t)j * c.L + c.lane]);
+    for (u32 j = 0; j < c.W; ++j) acc_mac_dev(acc, c.xs[j], c.powL[j * c.L + c.lane]);
     r = acc_reduce(acc, c.m);
     if (neg && r) r = c.m.q - r;
   }
@@ -1037,15 +1040,36 @@ __device__ __forceinline__ void wave_divmod(const WaveDecodeCtx& c, u64 n, const
 }
 
 __global__ __launch_bounds__(256) void decode_wave_kernel(const u64* __restrict__ noisy, u64* __restrict__ out,
-                                                           u32 count, DecodeTables t) {
-  __shared__ u64 lds[4 * 64];
+                                                           u32 count, u32 stage_z, DecodeTables t) {
+  // LDS: CRT table [L][W] | power table [W][L] | per wave: 64-word scratch (+ this ciphertext's residues)
+  extern __shared__ u64 dws[];
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const u32 d = blockIdx.x * 4 + wave;
-  if (d >= count) return;                           // whole waves exit together
   const u32 W = t.W, L = t.L, l = t.ell;
-  WaveDecodeCtx c{t, lds + wave * 64, lane, W, L, t.mods[lane < L ? lane : 0], lane < L, lane < W,
+  u64* qiL = dws;
+  u64* powL = dws + (size_t)L * W;
+  u64* smallL = dws + (size_t)2 * L * W;                 // mu_dp | dpow (padded) | mu_td | td, W+2 words each
+  u64* wbase = smallL + (size_t)4 * (W + 2) + (size_t)wave * (64 + (stage_z ? L * l : 0));
+  for (u32 x = threadIdx.x; x < L * W; x += 256) {
+    qiL[x] = t.qi[x];
+    powL[x] = t.pow64T[x];
+  }
+  for (u32 x = threadIdx.x; x < W + 2; x += 256) {
+    smallL[x] = t.mu_dp[x];
+    smallL[(W + 2) + x] = x < W ? t.dpow[x] : 0;
+    smallL[2 * (W + 2) + x] = t.mu_td[x];
+    smallL[3 * (W + 2) + x] = t.td[x];
+  }
+  const u32 d = blockIdx.x * 4 + wave;
+  const bool live = d < count;                      // wave-uniform
+  u64* zs = wbase + 64;
+  if (live && stage_z)
+    for (u32 x = lane; x < L * l; x += 64) zs[x] = noisy[(size_t)d * L * l + x];
+  __syncthreads();
+  if (!live) return;
+  WaveDecodeCtx c{t, qiL, powL, wbase, lane, W, L, t.mods[lane < L ? lane : 0], lane < L, lane < W,
                   lane < W ? t.Q[lane] : 0, lane < W ? t.halfQ[lane] : 0};
-  const u64* z = noisy + (size_t)d * L * l + (size_t)(c.limb_on ? lane : 0) * l;   // this limb's l residues
+  // this limb's l residues
+  const u64* z = (stage_z ? zs : noisy + (size_t)d * L * l) + (size_t)(c.limb_on ? lane : 0) * l;
   const u64 dm = t.dmod[c.limb_on ? lane : 0], dmp = t.dmodp[c.limb_on ? lane : 0];
   const u64 q = c.m.q;
   auto tmp = [&](u32 i) -> u64 { return submod(mulmod_shoup(z[i], dm, dmp, q), z[i + 1], q); };   // :19-27
@@ -1057,7 +1081,7 @@ __global__ __launch_bounds__(256) void decode_wave_kernel(const u64* __restrict_
   // reduce_modulo_poly (:154-178)
   const u64 dpw = lane < W ? t.dpow[lane] : 0, hdw = lane < W ? t.half_dpow[lane] : 0;
   u64 qq, r;
-  wave_divmod(c, x, t.mu_dp, t.dpow, dpw, qq, r);
+  wave_divmod(c, x, smallL, smallL + (W + 2), dpw, qq, r);
   if (__ballot(r != 0) == 0) neg = false;
   if (wave_cmp(r, hdw) > 0) {
     r = wave_sub(dpw, r, lane);
@@ -1073,7 +1097,7 @@ __global__ __launch_bounds__(256) void decode_wave_kernel(const u64* __restrict_
     u64 hi = p >> 63, lo2 = p << 1;
     u64 s = lo2 + dlw;
     u64 num = wave_normalize(s, hi + (s < dlw), 0, lane);
-    wave_divmod(c, num, t.mu_td, t.td, tdw, qq, r);
+    wave_divmod(c, num, smallL + 2 * (W + 2), smallL + 3 * (W + 2), tdw, qq, r);
     const bool qzero = __ballot(qq != 0) == 0;
     nres = wave_to_rns(c, qq, pneg && !qzero);
   }
@@ -1693,7 +1717,15 @@ hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeT
   }
   static int variant = [] { const char* e = getenv("PVW_DECODE_VARIANT"); return e ? atoi(e) : 0; }();
   if (variant == 0 && t.L <= 64 && t.W + 2 <= 64) {
-    decode_wave_kernel<<<dim3((u32)((count + 3) / 4)), dim3(256), 0, s>>>(noisy, out, (u32)count, t);
+    const size_t tab = ((size_t)2 * t.L * t.W + 4 * (t.W + 2)) * 8, scratch = (size_t)4 * 64 * 8, zb = (size_t)4 * t.L * t.ell * 8;
+    const u32 stage_z = (tab + scratch + zb <= 96 * 1024) ? 1u : 0u;
+    const size_t wl = tab + scratch + (stage_z ? zb : 0);
+    static bool wattr = false;
+    if (!wattr) {
+      hipFuncSetAttribute((const void*)decode_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      wattr = true;
+    }
+    decode_wave_kernel<<<dim3((u32)((count + 3) / 4)), dim3(256), wl, s>>>(noisy, out, (u32)count, stage_z, t);
     return hipGetLastError();
   }
   decode_kernel<<<dim3((u32)((count + 63) / 64)), dim3(64), lds, s>>>(noisy, out, (u32)count, t);
