@@ -775,7 +775,7 @@ __global__ __launch_bounds__(1024) void decrypt_mac_kernel(const u64* __restrict
 // decrypt_mac, dealer-grouped form: one workgroup serves DG dealers, so every s-hat pair fetched
 // (through L2) is used DG times and the vector-memory instruction count per streamed byte drops
 // from 2 to 1 + 1/DG.  Thread (g, e) as above; UJ j-steps are issued together.
-template <int DG, int UJ, int MAXT>
+template <int DG, int UJ, int MAXT, bool NO_S = false>
 __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __restrict__ c1s,
                                                                     const u64* __restrict__ shat,
                                                                     const u64* __restrict__ c2col,
@@ -802,7 +802,8 @@ __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __
       v2u64 y[UJ], x[UJ][DG];
 #pragma unroll
       for (int u = 0; u < UJ; ++u) {
-        y[u] = sp[(size_t)(j + u * c) * pairs];
+        if constexpr (NO_S) y[u] = (v2u64){(u64)j + 3, (u64)j + 5};    // timing experiment: no s-hat traffic
+        else y[u] = sp[(size_t)(j + u * c) * pairs];
 #pragma unroll
         for (int dd = 0; dd < DG; ++dd) x[u][dd] = __builtin_nontemporal_load(cp[dd] + (size_t)(j + u * c) * pairs);
       }
@@ -1628,6 +1629,10 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
       case 30: PVW_DEC_GROUPED(1, 8); break;
       case 40: PVW_DEC_GROUPED(3, 2); break;
       case 41: PVW_DEC_GROUPED(4, 2); break;
+      case 50:   // timing experiment only (wrong results): the c1 stream without the s-hat loads
+        decrypt_mac_grouped_kernel<2, 2, 512, true><<<dim3((u32)((dealers + 1) / 2)), dim3(threads), lds, s>>>(
+            c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers);
+        break;
       default: PVW_DEC_GROUPED(2, 2); break;
     }
 #undef PVW_DEC_GROUPED

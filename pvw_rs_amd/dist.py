@@ -56,6 +56,33 @@ def load_broadcast_crs(params: PvwParameters, t, repr: int = _ffi.REPR_NTT) -> P
     return PvwCrs(params)
 
 
+def shard_dealers(num_dealers: int, world: int, rank: int) -> Tuple[int, int]:
+    """Dealer ciphertexts [lo, hi) decrypted by `rank` (batched decrypt_party_shares, config 5)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return num_dealers * rank // world, num_dealers * (rank + 1) // world
+
+
+def all_gather_decrypted(local_values, num_dealers: int, device=None) -> np.ndarray:
+    """The one collective of the sharded decrypt: every rank contributes the u64 results of its
+    dealer shard (decoded on its GPU) and receives all `num_dealers` of them.  8 bytes per
+    ciphertext -- an RCCL all_gather over xGMI with backend "nccl", gloo in the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = max(shard_dealers(num_dealers, world, r)[1] - shard_dealers(num_dealers, world, r)[0] for r in range(world))
+    mine = torch.zeros(per, dtype=torch.int64, device=device)
+    vals = np.asarray(local_values, dtype=np.uint64).view(np.int64)
+    mine[: len(vals)] = torch.from_numpy(vals.copy()).to(mine.device)
+    parts = [torch.zeros(per, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = np.zeros(num_dealers, dtype=np.uint64)
+    for r in range(world):
+        lo, hi = shard_dealers(num_dealers, world, r)
+        out[lo:hi] = parts[r][: hi - lo].cpu().numpy().view(np.uint64)
+    return out
+
+
 def gather_rows(local: np.ndarray, lo: int, hi: int, total_rows: int, dst: int = 0) -> Optional[np.ndarray]:
     """Test/diagnostic helper: gather row shards [lo, hi) of every rank on `dst` (gloo or nccl)."""
     import torch.distributed as dist

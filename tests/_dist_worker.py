@@ -56,6 +56,12 @@ def main():
         ct = P.encrypt(scalars, gpk, seed)                              # same seed on every rank
         c1_loc, c2_loc = ct.c1, ct.c2
         g_hat = p.gadget_polynomial(P.REPR_NTT)
+    # config-5 shape: dealers sharded over the ranks, D x u64 results all-gathered
+    Dn = 9
+    dlo, dhi = D.shard_dealers(Dn, world, rank)
+    local_vals = np.arange(dlo, dhi, dtype=np.uint64) * np.uint64(3) + np.uint64(1)
+    got_all = D.all_gather_decrypted(local_vals, Dn)
+    assert got_all.tolist() == [3 * d + 1 for d in range(Dn)], got_all
     c1 = D.gather_rows(c1_loc, clo, chi, k)
     c2 = D.gather_rows(c2_loc, lo, hi, n)
     if rank == 0:

@@ -49,6 +49,9 @@ def test_shard_ranges_partition():
         assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         D.shard_ranges(4, 4, 2, 2)
+    for Dn, world in [(8192, 8), (9, 2), (3, 4)]:
+        parts = [D.shard_dealers(Dn, world, r) for r in range(world)]
+        assert parts[0][0] == 0 and parts[-1][1] == Dn and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
 
 
 def test_world2_gloo_cpu():
