@@ -397,7 +397,7 @@ def bench_decrypt(args, world, rank, local_rank, dev):
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": desc, "dealers_per_gpu": D, "k": k, "l": l, "rns_limbs": L,
                    "q_bits": int(params.q_total().bit_length())},
-        "roofline": {"bound": "hbm", "kernel": "decrypt_mac_grouped_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "decrypt_mac_fw_kernel" if L * l // 2 >= 128 else "decrypt_mac_grouped_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6, "launches_timed": launches},
         "kernel_ms_per_step": {name: v[0] / max(args.steps, 1) for name, v in kt.items()},

@@ -851,6 +851,124 @@ __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __
   }
 }
 
+// decrypt_mac, full-width form.  A wave-wide load moves at most 1 KiB and the chip sustains a fixed
+// number of them per second, so a polynomial of L*l/2 = 64*FW + rem slot pairs is split into FW waves
+// that own 64 pairs each (every load full width) plus ONE remainder wave whose lanes cover
+// G = 64/rem' consecutive j at once (rem' = rem rounded up to a power of two): its loads are G
+// segments of rem' pairs, again (nearly) full width.  The grouped form above leaves 15 % (L*l/2 = 272)
+// to 47 % (68) of the lanes of its last wave idle on every load.  Two dealers per workgroup.
+template <int DG, int UJ>
+__global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restrict__ c1s,
+                                                               const u64* __restrict__ shat,
+                                                               const u64* __restrict__ c2col,
+                                                               u64* __restrict__ noisy,
+                                                               const Mod* __restrict__ mods, u32 k, u32 ell,
+                                                               u32 pairs, u32 FW, u32 cfull, u32 remp, u32 crem,
+                                                               u32 dealers) {
+  extern __shared__ v2u64 dl[];                        // [DG][waves*64] partial sums
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 nfull = cfull * FW, rem = pairs - FW * 64;
+  const bool is_full = wave < nfull;                   // wave-uniform
+  const u32 d0 = blockIdx.x * DG;
+  u32 e, jstart, jstep;
+  bool active;
+  if (is_full) {
+    const u32 g = wave / FW, fw = wave % FW;
+    e = fw * 64 + lane;
+    jstart = g;
+    jstep = cfull;
+    active = true;
+  } else {
+    const u32 rw = wave - nfull;                       // replica among the remainder waves
+    const u32 G = 64 / remp, jsub = lane / remp, er = lane % remp;
+    e = FW * 64 + er;
+    jstart = rw * G + jsub;
+    jstep = crem * G;
+    active = er < rem;
+  }
+  const v2u64* sp = reinterpret_cast<const v2u64*>(shat) + (active ? e : 0);
+  const v2u64* cp[DG];
+#pragma unroll
+  for (int dd = 0; dd < DG; ++dd) {
+    const u32 d = (d0 + dd) < dealers ? (d0 + dd) : (dealers - 1);
+    cp[dd] = reinterpret_cast<const v2u64*>(c1s) + (size_t)d * k * pairs + (active ? e : 0);
+  }
+  Acc a0[DG], a1[DG];
+#pragma unroll
+  for (int dd = 0; dd < DG; ++dd) { acc_zero(a0[dd]); acc_zero(a1[dd]); }
+  if (active) {
+    u32 j = jstart;
+    for (; j + (UJ - 1) * jstep < k; j += UJ * jstep) {
+      v2u64 y[UJ], x[UJ][DG];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        y[u] = sp[(size_t)(j + u * jstep) * pairs];
+#pragma unroll
+        for (int dd = 0; dd < DG; ++dd) x[u][dd] = __builtin_nontemporal_load(cp[dd] + (size_t)(j + u * jstep) * pairs);
+      }
+#pragma unroll
+      for (int u = 0; u < UJ; ++u)
+#pragma unroll
+        for (int dd = 0; dd < DG; ++dd) {
+          acc_mac_dev(a0[dd], x[u][dd].x, y[u].x);
+          acc_mac_dev(a1[dd], x[u][dd].y, y[u].y);
+        }
+    }
+    for (; j < k; j += jstep) {
+      v2u64 y0 = sp[(size_t)j * pairs];
+#pragma unroll
+      for (int dd = 0; dd < DG; ++dd) {
+        v2u64 x0 = cp[dd][(size_t)j * pairs];
+        acc_mac_dev(a0[dd], x0.x, y0.x);
+        acc_mac_dev(a1[dd], x0.y, y0.y);
+      }
+    }
+  }
+  const u32 limb = active ? (2 * e) / ell : 0;
+  const Mod m = mods[limb];
+  const u32 T = blockDim.x;
+#pragma unroll
+  for (int dd = 0; dd < DG; ++dd) {
+    v2u64 part;
+    part.x = acc_reduce(a0[dd], m);
+    part.y = acc_reduce(a1[dd], m);
+    dl[dd * T + threadIdx.x] = part;
+  }
+  __syncthreads();
+  // one owner per pair sums the partials of its replicas and finishes: full waves of replica 0 and
+  // the lanes with jsub == 0 of remainder replica 0
+  bool owner;
+  if (is_full) owner = wave < FW;
+  else owner = active && wave == nfull && lane < remp;
+  if (owner) {
+#pragma unroll
+    for (int dd = 0; dd < DG; ++dd) {
+      if (d0 + dd >= dealers) continue;
+      v2u64 sres = (v2u64){0, 0};
+      if (is_full) {
+        for (u32 g = 0; g < cfull; ++g) {
+          v2u64 tq = dl[dd * T + (g * FW + wave) * 64 + lane];
+          sres.x = addmod(sres.x, tq.x, m.q);
+          sres.y = addmod(sres.y, tq.y, m.q);
+        }
+      } else {
+        const u32 G = 64 / remp;
+        for (u32 rw = 0; rw < crem; ++rw)
+          for (u32 js = 0; js < G; ++js) {
+            v2u64 tq = dl[dd * T + (nfull + rw) * 64 + js * remp + lane];
+            sres.x = addmod(sres.x, tq.x, m.q);
+            sres.y = addmod(sres.y, tq.y, m.q);
+          }
+      }
+      const size_t o = (size_t)(d0 + dd) * pairs + e;
+      v2u64 c2 = reinterpret_cast<const v2u64*>(c2col)[o];
+      sres.x = submod(sres.x, c2.x, m.q);
+      sres.y = submod(sres.y, c2.y, m.q);
+      reinterpret_cast<v2u64*>(noisy)[o] = sres;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // decode: decode_scalar_pvw_rns (decryption.rs:10-58) on the device, one thread per ciphertext.
 // Big integers live in LDS with the thread index as the fast axis (word j of thread t at [j][t]).
@@ -1607,9 +1725,52 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
     c = 1;
     threads = 1024;
   }
+  // variant 0 (default) picks by shape: the full-width form from 128 slot pairs per polynomial up, the
+  // dealer-grouped form below that (profiles/r01_variant_sweep.txt, profiles/r01d_decrypt_sweep.txt).
+  // The environment is read on every launch so that the tests can walk the variants in one process.
+  int variant = 0, cenv = 0;
+  if (const char* e = getenv("PVW_DEC_VARIANT")) variant = atoi(e);
+  if (const char* e = getenv("PVW_DEC_C")) cenv = atoi(e);
+  if (variant == 0) variant = pairs >= 128 && pairs <= 1024 ? 61 : 10;
+  if (variant < 60 && pairs <= 1024 && cenv > 0 && (u32)cenv * pairs <= 1024 && (u32)cenv <= k) {
+    c = (u32)cenv;
+    threads = ((c * pairs + 63) / 64) * 64;
+  }
   const size_t lds = (size_t)threads * sizeof(v2u64);
-  // default: dealer-grouped DG=2, UJ=2 (best of the round-1 sweep: profiles/r01_variant_sweep.txt)
-  static int variant = [] { const char* e = getenv("PVW_DEC_VARIANT"); return e ? atoi(e) : 10; }();
+  if (variant >= 60 && pairs <= 1024) {
+    const u32 FW = pairs / 64, rem = pairs % 64;
+    u32 remp = 0;
+    if (rem) { remp = 1; while (remp < rem) remp <<= 1; }
+    // replicas of the full waves (each takes every cfull-th j): the largest ODD count that fits 16 waves.
+    // Measured at l=16, L=34 (272 pairs): 1, 2 replicas 398-402 us, 3 replicas 357 us; even counts lose on
+    // every shape tried, and one 13-wave workgroup per CU beats two 5-wave ones.
+    const u32 has_rem = rem ? 1u : 0u;
+    u32 cfull = 0;
+    if (FW) {
+      cfull = (16 - has_rem) / FW;
+      if (cfull > 1 && cfull % 2 == 0) --cfull;
+      if (cfull > 7) cfull = 7;
+      if (cenv > 0 && (u32)cenv * FW + has_rem <= 16) cfull = (u32)cenv;
+      if (cfull > k) cfull = k;
+    }
+    const u32 crem = rem ? (FW ? 1 : 4) : 0;
+    const u32 waves = cfull * FW + crem;
+    if (waves >= 1 && waves <= 16) {
+      const u32 thr = waves * 64;
+#define PVW_DEC_FW(DGv, UJv)                                                                                       \
+  decrypt_mac_fw_kernel<DGv, UJv><<<dim3((u32)((dealers + DGv - 1) / DGv)), dim3(thr), (size_t)DGv * thr * sizeof(v2u64), s>>>( \
+      c1s, shat, c2col, noisy, t.mods, k, ell, pairs, FW, cfull, remp, crem, (u32)dealers)
+      switch (variant) {
+        case 61: PVW_DEC_FW(2, 4); break;
+        case 62: PVW_DEC_FW(1, 4); break;
+        case 63: PVW_DEC_FW(1, 8); break;
+        case 64: PVW_DEC_FW(3, 2); break;
+        default: PVW_DEC_FW(2, 2); break;
+      }
+#undef PVW_DEC_FW
+      return hipGetLastError();
+    }
+  }
   if (variant >= 10 && ny == 1) {
     // dealer-grouped kernels: variant 1x = DG 2, 2x = DG 4; x = 0: UJ 2, 1: UJ 4 (DG 2) / UJ 1 (DG 4)
 #define PVW_DEC_GROUPED(DGv, UJv)                                                                         \

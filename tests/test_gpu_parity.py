@@ -299,6 +299,33 @@ def test_ragged_geometries_against_c_oracle(n, k, l, L):
     assert np.array_equal(noisy, orc.decrypt_noisy(sk, c1s, c2col))
 
 
+@pytest.mark.parametrize("k,l,L,D", [
+    (37, 16, 34, 5),      # 272 slot pairs (configs 4/5): four full waves + a 16-pair remainder wave
+    (20, 32, 9, 4),       # 144 pairs: two full waves + remainder
+    (64, 8, 17, 7),       # 68 pairs (configs 2/3): one full wave + a 4-pair remainder
+    (9, 8, 3, 3),         # 12 pairs: remainder waves only
+    (11, 16, 8, 2),       # 64 pairs: no remainder
+])
+def test_decrypt_mac_launch_shapes_agree_with_c_oracle(k, l, L, D, monkeypatch):
+    # every launch shape of decrypt_party_value's <sk, c1> (decryption.rs:271-291) gives the oracle's
+    # noisy polynomials: the shape-selected default, the dealer-grouped form and the full-width form,
+    # each with 1, 2, 3 j-replicas
+    moduli = M.bench_moduli(L)
+    p = build_params(3, k, l, moduli)
+    orc = O.Oracle(moduli, l)
+    c1s = orc.fill_uniform(SEED, M.DOM_CRS, 0, D * k).reshape(D, k, L, l)
+    c2col = orc.fill_uniform(SEED, M.DOM_PK, 0, D).reshape(D, L, l)
+    sk = O.sample_cbd(SEED, M.DOM_SK, 0, k, l, 0.5)
+    want = orc.decrypt_noisy(sk, c1s, c2col)
+    cts = [P.PvwCiphertext(c1s[d], np.repeat(c2col[d][None], 3, axis=0), p, P.REPR_NTT) for d in range(D)]
+    key = P.SecretKey.from_coefficients(p, sk)
+    for variant, c in [(0, 0), (10, 0), (10, 2), (10, 3), (11, 0), (60, 0), (60, 1), (60, 2), (61, 3), (62, 0), (64, 0)]:
+        monkeypatch.setenv("PVW_DEC_VARIANT", str(variant))
+        monkeypatch.setenv("PVW_DEC_C", str(c))
+        _, noisy = P.api._decrypt_batch(p, cts, key, 0, return_noisy=True)
+        assert np.array_equal(noisy, want), (variant, c)
+
+
 @pytest.mark.parametrize("D", [1, 4, 7])
 def test_multi_dealer_encrypt_equals_separate_encrypts(D):
     # encrypt_all_party_shares (encryption.rs:253-286) batched four dealers per pass over B-hat
