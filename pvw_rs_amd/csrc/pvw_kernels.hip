@@ -34,14 +34,15 @@ typedef u64 v2u64 __attribute__((ext_vector_type(2)));  // one 16-byte lane acce
 // grid = row_blocks * L workgroups of 256 threads; the 4 waves split the j range, each
 // streaming a contiguous run of 1-KiB tiles; r-hat slices are staged in wave-private LDS.
 // ------------------------------------------------------------------------------------
-template <int ELL, int U, bool NT, bool DBUF>
-__global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection sb,
+template <int ELL, int U, bool NT, bool DBUF, bool ILV = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSection sb,
                                                         const u64* __restrict__ rhat,
                                                         const Mod* __restrict__ mods, u32 k, u32 L) {
   constexpr int HALF = ELL / 2;   // 16-byte slot pairs per polynomial limb
   constexpr int R = 128 / ELL;    // rows per tile
   constexpr int JC = ELL <= 16 ? 64 : (ELL == 32 ? 32 : 16);  // j per staged r-hat chunk (LDS <= 32 KiB)
-  __shared__ v2u64 lds[4 * JC * HALF];
+  __shared__ v2u64 lds[NW * JC * HALF];
+  static_assert(JC * HALF >= 64, "the wave partials reuse the r-hat slabs");
 
   // section a = A-hat rows (c1), section b = B-hat rows (c2): one launch covers both
   const u32 limb = blockIdx.x % L;
@@ -54,9 +55,12 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
   const u32 nrows = in_a ? sa.nrows : sb.nrows;
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 sp = lane % HALF, rho = lane / HALF;
-  const u32 kq = (k + 3) / 4;
-  const u32 j0 = wave * kq < k ? wave * kq : k;
-  const u32 j1 = (j0 + kq) < k ? (j0 + kq) : k;
+  // ILV (needs k % (NW*U) == 0): the NW waves interleave groups of U tiles, so the workgroup reads ONE
+  // contiguous stream; local tile t of a wave is global tile (t / U) * NW*U + wave * U + t % U
+  const u32 kq = ILV ? k / NW : (k + NW - 1) / NW;
+  const u32 j0 = ILV ? 0 : (wave * kq < k ? wave * kq : k);
+  const u32 j1 = ILV ? kq : ((j0 + kq) < k ? (j0 + kq) : k);
+  auto gmap = [&](u32 t) -> u32 { return ILV ? (t / U) * NW * U + wave * U + t % U : t; };
 
   const v2u64* Mp =
       reinterpret_cast<const v2u64*>(M + ((size_t)rb * L + limb) * (size_t)k * 128) + lane;
@@ -70,15 +74,15 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
   for (u32 jc = j0; jc < j1; jc += JC) {
     const u32 cnt = (j1 - jc) < (u32)JC ? (j1 - jc) : (u32)JC;
     __builtin_amdgcn_wave_barrier();
-    for (u32 idx = lane; idx < cnt * HALF; idx += 64) lw[idx] = rp[(size_t)jc * HALF + idx];
+    for (u32 idx = lane; idx < cnt * HALF; idx += 64) lw[idx] = rp[(size_t)gmap(jc + idx / HALF) * HALF + idx % HALF];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    const v2u64* mp = Mp + (size_t)jc * 64;
     u32 jj = 0;
-    auto ld = [&](size_t tile) -> v2u64 {
-      if constexpr (NT) return __builtin_nontemporal_load(mp + tile * 64);
-      else return mp[tile * 64];
+    auto ld = [&](u32 tile) -> v2u64 {
+      const v2u64* p = Mp + (size_t)gmap(jc + tile) * 64;
+      if constexpr (NT) return __builtin_nontemporal_load(p);
+      else return *p;
     };
     if constexpr (DBUF) {
       // two register buffers: the next U tiles are in flight while the current U are consumed
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
       }
     }
     for (; jj < cnt; ++jj) {
-      v2u64 xv = mp[(size_t)jj * 64];
+      v2u64 xv = ld(jj);
       v2u64 y = lw[jj * HALF + sp];
       acc_mac_dev(a0, xv.x, y.x);
       acc_mac_dev(a1, xv.y, y.y);
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
     if (row < nrows) {
       v2u64 s = lds[lane];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) {
+      for (int w = 1; w < NW; ++w) {
         v2u64 t = lds[w * 64 + lane];
         s.x = addmod(s.x, t.x, m.q);
         s.y = addmod(s.y, t.y, m.q);
@@ -1561,15 +1565,12 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
   }
 
 // PVW_MAC_VARIANT (debug/tuning): selects the streaming schedule of mac_rows for l = 8 / 16
-//   0 (default) U=8 double-buffered nt | 1 same, default cache policy | 2 U=4 dbuf nt | 3 U=16 dbuf nt
+//   0 (default) by shape, see below | 17 U=8 (l=8) / 16 (l=16) double-buffered nt, not interleaved | 1 same, default cache policy | 2 U=4 dbuf nt | 3 U=16 dbuf nt
 //   4 U=16 single buffer nt | 5 U=8 single buffer nt | 6 U=16 single buffer, default policy
-//   7 continuous stream U=8 nt | 8 continuous stream U=16 nt
-static int mac_variant() {
-  static int v = [] {
-    const char* e = getenv("PVW_MAC_VARIANT");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
+//   7 continuous stream U=8 nt | 8 continuous stream U=16 nt | 9/10/11 waves interleave groups of U=8/16/4 tiles
+static int mac_variant() {   // read per launch: the parity tests walk the variants in one process
+  const char* e = getenv("PVW_MAC_VARIANT");
+  return e ? atoi(e) : 0;
 }
 template <int E>
 static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacSection& sa, const MacSection& sb,
@@ -1584,11 +1585,28 @@ static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacS
       case 6: mac_rows_kernel<E, 16, false, false><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       case 7: mac_rows_stream_kernel<E, 8, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       case 8: mac_rows_stream_kernel<E, 16, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
+      case 9: if (k % 32 == 0) { mac_rows_kernel<E, 8, true, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 10: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 11: if (k % 16 == 0) { mac_rows_kernel<E, 4, true, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 12: if (k % 64 == 0) { mac_rows_kernel<E, 8, true, true, true, 8><<<grid, dim3(512), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 13: if (k % 128 == 0) { mac_rows_kernel<E, 8, true, true, true, 16><<<grid, dim3(1024), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 14: if (k % 128 == 0) { mac_rows_kernel<E, 16, true, true, true, 8><<<grid, dim3(512), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 15: if (k % 64 == 0) { mac_rows_kernel<E, 4, true, true, true, 16><<<grid, dim3(1024), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 16: if (k % 64 == 0) { mac_rows_kernel<E, 8, true, false, true, 8><<<grid, dim3(512), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
       default: break;
     }
   }
-  // defaults from the round-1 sweep (profiles/r01_variant_sweep.txt): 8 tiles per buffer at l = 8,
-  // 16 at l >= 16 (longer per-workgroup streams), always double-buffered non-temporal loads
+  // defaults from the round-1 sweeps (profiles/r01_variant_sweep.txt, r01d_mac_ilv_sweep.txt): always
+  // double-buffered non-temporal loads; when k allows it the four waves interleave groups of 16 tiles so the
+  // workgroup reads one contiguous stream (+5 % at l = 16, k = 512; +2 % at n = 16384; within noise at config 3)
+  if constexpr (E <= 16) {
+    if (variant != 0) {
+      // an explicit schedule that does not apply to this k falls back to the non-interleaved default
+    } else if (k % 64 == 0) {
+      mac_rows_kernel<E, 16, true, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L);
+      return;
+    }
+  }
   if constexpr (E == 16) {
     mac_rows_kernel<E, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L);
     return;

@@ -299,6 +299,27 @@ def test_ragged_geometries_against_c_oracle(n, k, l, L):
     assert np.array_equal(noisy, orc.decrypt_noisy(sk, c1s, c2col))
 
 
+@pytest.mark.parametrize("n,k,l,L", [(40, 256, 8, 3), (21, 128, 16, 2), (9, 64, 8, 2), (5, 24, 8, 2)])
+def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
+    # every streaming schedule of mac_rows (PVW_MAC_VARIANT) computes the same c1, c2 (encryption.rs:158,177-200)
+    moduli = M.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    scalars = [(i * 77 + 5) % (1 << 32) for i in range(n)]
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(SEED, M.DOM_CRS, 0, k * k).reshape(k, k, L, l)
+    b_hat = orc.fill_uniform(SEED, M.DOM_PK, 0, n * k).reshape(n, k, L, l)
+    r = O.sample_cbd(SEED, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
+    e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
+    c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), np.array(scalars, dtype=np.uint64), r, e1, e2)
+    for variant in range(0, 18):
+        monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
+        ct = P.encrypt(scalars, gpk, SEED)
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
+
+
 @pytest.mark.parametrize("k,l,L,D", [
     (37, 16, 34, 5),      # 272 slot pairs (configs 4/5): four full waves + a 16-pair remainder wave
     (20, 32, 9, 4),       # 144 pairs: two full waves + remainder
