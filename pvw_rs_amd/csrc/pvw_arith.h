@@ -151,15 +151,19 @@ PVW_HD void acc_add(Acc& a, const Acc& b) {  // a += b  (cross-wave reduction)
 }
 // value = (ll + cll*2^64) + ((lh + clh*2^64) + (hl + chl*2^64))*2^32 + (hh + chh*2^64)*2^64,
 // reduced mod q.  The total is < 2^160 for <= 2^32 terms, held in three 64-bit words.
-PVW_HD u64 acc_reduce(const Acc& a, const Mod& m) {
+PVW_HD void acc_words(const Acc& a, u64& t0, u64& t1, u64& t2) {   // total = t2:t1:t0
   u128 mid = (u128)a.lh + a.hl;                                  // < 2^65
   u128 midc = (u128)a.clh + a.chl + (u64)(mid >> 64);            // weight 2^96
   u64 midlo = (u64)mid;                                          // weight 2^32
   u128 w0 = (u128)a.ll + ((u128)(midlo & 0xffffffffULL) << 32);
-  u64 t0 = (u64)w0;
+  t0 = (u64)w0;
   u128 w1 = (w0 >> 64) + (u128)a.cll + (midlo >> 32) + (midc << 32) + a.hh;
-  u64 t1 = (u64)w1;
-  u64 t2 = (u64)(w1 >> 64) + a.chh;                              // total = t2:t1:t0
+  t1 = (u64)w1;
+  t2 = (u64)(w1 >> 64) + a.chh;
+}
+PVW_HD u64 acc_reduce(const Acc& a, const Mod& m) {
+  u64 t0, t1, t2;
+  acc_words(a, t0, t1, t2);
   u64 h = reduce128(t1, t2, m);                                  // (t2:t1) mod q
   return reduce128(t0, h, m);                                    // (h*2^64 + t0) mod q
 }

@@ -407,8 +407,8 @@ def test_multi_dealer_encrypt_l16_and_sharded():
 
 
 @pytest.mark.parametrize("l,moduli", [(8, [0xFFFFEE001]), (8, TEST_MODULI), (32, TEST_MODULI), (8, M.bench_moduli(17)),
-                                      (16, M.bench_moduli(34))])
-def test_device_decode_matches_model(l, moduli):
+                                      (16, M.bench_moduli(34)), (64, primes_1mod(128, 5))])
+def test_device_decode_matches_model(l, moduli, monkeypatch):
     # decode_scalar_pvw_rns (decryption.rs:10-58) on the device, fixed-width integers
     rng = np.random.default_rng(l + len(moduli))
     p = build_params(3, 4, l, moduli)
@@ -425,9 +425,13 @@ def test_device_decode_matches_model(l, moduli):
         cases.append([v % Q] * l)
         cases.append([(v * (j + 1)) % Q for j in range(l)])
     arr = np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64)
-    got = P.decode_scalar_pvw(p, arr)
-    assert got == [M.decode_scalar_pvw(z, m) for z in cases]
-    assert got == P.decode_scalar_pvw_host(p, arr)
+    want = [M.decode_scalar_pvw(z, m) for z in cases]
+    assert want == P.decode_scalar_pvw_host(p, arr)
+    # every device form: lifted chain with 4 / 2 / 8 waves per ciphertext, one wave per ciphertext with an
+    # RNS round trip per step, one thread per ciphertext
+    for variant in (0, 3, 4, 2, 1):
+        monkeypatch.setenv("PVW_DECODE_VARIANT", str(variant))
+        assert P.decode_scalar_pvw(p, arr) == want, variant
 
 
 def test_concurrent_encrypt_calls_on_one_context():

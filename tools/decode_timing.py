@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Cycle counts of the phases of decode_chain_kernel (PVW_DECODE_TIMING, tuning aid; run on the GPU box)."""
+import os, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import pvw_model as M
+import pvw_rs_amd as P
+
+L, l, count = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+moduli = M.bench_moduli(L)
+p = (P.PvwParametersBuilder().set_parties(3).set_dimension(4).set_l(l).set_moduli(moduli)
+     .set_secret_variance(0.5).set_error_bounds(100, 200).build())
+rng = np.random.default_rng(1)
+arr = np.stack([rng.integers(0, q, size=(count, l), dtype=np.uint64) for q in moduli], axis=1)
+for variant in sys.argv[4:] or ["0"]:
+    os.environ["PVW_DECODE_VARIANT"] = variant
+    for mode, name in ((1, "staging"), (2, "phase1 lifts + first division"), (3, "chain"), (4, "step: sub_centre"), (5, "step: 2|p|+Delta"), (6, "step: division")):
+        os.environ["PVW_DECODE_TIMING"] = str(mode)
+        P.decode_scalar_pvw(p, arr)
+        got = np.array(P.decode_scalar_pvw(p, arr), dtype=np.float64)
+        print(f"variant {variant} {name}: median {np.median(got):.0f} min {got.min():.0f} max {got.max():.0f} ticks (100 MHz clock64 => x10 ns)")
+    os.environ.pop("PVW_DECODE_TIMING")
