@@ -211,7 +211,7 @@ def main():
     }
     if Dm > 0:
         out["metric"] = ("party-ciphertexts/s for encrypt_all_party_shares (D dealers x n parties, "
-                         + ("16" if gemm_path else "4") + " dealers per pass over B-hat)")
+                         + ("batches of 16, up to 64 per launch" if gemm_path else "4") + " dealers per pass over B-hat)")
         out["unit"] = "party-ciphertexts/s"
         out["roofline"]["kernel"] = "gemm_digits_kernel (i8 MFMA)" if gemm_path else "mac_rows_multi_kernel"
         out["roofline"]["modular_macs_per_s"] = L * l * (n_per * k + rows_a * k) * nv / mac_avg_s if mac_avg_s > 0 else 0.0
@@ -274,7 +274,7 @@ def main():
 
 def bench_keygen(args, world, rank, local_rank, dev):
     """Batched key generation b_i = s_i*A + e_i (public_key.rs:111-147, crs.rs:138-171) for the parties
-    of this rank: 16 parties per pass over the transposed CRS on the matrix cores (gemm_digits)."""
+    of this rank: batches of 16 parties, up to 128 per launch, against the transposed CRS on the matrix cores (gemm_digits)."""
     import numpy as np
     import torch  # noqa: F401
 

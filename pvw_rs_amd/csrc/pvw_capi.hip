@@ -730,12 +730,22 @@ static int32_t load_rows_host(pvw_ctx* c, u64* M, u32 shard_lo, u32 shard_hi, u3
   ws_release(c, w);
   return rc;
 }
+// dealers per gemm_digits launch: PVW_GEMM_VB batches of 16 (they share one pass over the matrix through L2)
+static u32 gemm_vb() {
+  static u32 v = [] {
+    const char* e = getenv("PVW_GEMM_VB");
+    int x = e ? atoi(e) : 4;
+    return (u32)(x < 1 ? 1 : (x > 8 ? 8 : x));
+  }();
+  return v;
+}
 static int32_t ws_gemm_buffers(pvw_ctx* c, Workspace* w) {
-  if (!w->vhat16) PVW_HIP(hipMalloc((void**)&w->vhat16, (size_t)16 * c->k * c->poly() * 8));
-  if (!w->yd) PVW_HIP(hipMalloc((void**)&w->yd, yd_bytes(16, c->k, c->L, c->l)));
-  if (!w->sy) PVW_HIP(hipMalloc((void**)&w->sy, sy_bytes(16, c->L, c->l)));
-  if (!w->gtmpA && c->rowsA()) PVW_HIP(hipMalloc((void**)&w->gtmpA, gemm_tmp_words(c->rowsA(), c->L, c->l) * 8));
-  if (!w->gtmpB && c->rowsB()) PVW_HIP(hipMalloc((void**)&w->gtmpB, gemm_tmp_words(c->rowsB(), c->L, c->l) * 8));
+  const u32 vb = gemm_vb();
+  if (!w->vhat16) PVW_HIP(hipMalloc((void**)&w->vhat16, (size_t)16 * vb * c->k * c->poly() * 8));
+  if (!w->yd) PVW_HIP(hipMalloc((void**)&w->yd, yd_bytes(16 * vb, c->k, c->L, c->l)));
+  if (!w->sy) PVW_HIP(hipMalloc((void**)&w->sy, sy_bytes(16 * vb, c->L, c->l)));
+  if (!w->gtmpA && c->rowsA()) PVW_HIP(hipMalloc((void**)&w->gtmpA, (size_t)vb * gemm_tmp_words(c->rowsA(), c->L, c->l) * 8));
+  if (!w->gtmpB && c->rowsB()) PVW_HIP(hipMalloc((void**)&w->gtmpB, (size_t)vb * gemm_tmp_words(c->rowsB(), c->L, c->l) * 8));
   return PVW_OK;
 }
 // MFMA-tiled copies of the resident A-hat / B-hat sections
@@ -1200,7 +1210,7 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
     PVW_TRY(ws_gemm_buffers(c, w));
     PVW_TRY(ensure_xm(c, s));
   }
-  const size_t group = use_gemm ? 16 : 4;
+  const size_t group = use_gemm ? (size_t)16 * gemm_vb() : 4;
   u64* vh = use_gemm ? w->vhat16 : w->rhat;
   for (size_t d0 = 0; d0 < D; d0 += group) {
     const u32 nv = (u32)((D - d0) < group ? (D - d0) : group);
@@ -1228,7 +1238,7 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
         PVW_HIP(launch_vec_digits(vh, (size_t)k * P, w->yd, w->sy, nv, k, L, l, c->dt, s));
       }
       ProfScope ps(c, "gemm_digits", s);
-      GemmSection a{c->xmA, c1g, c1g, w->gtmpA, rA, 0}, b{c->xmB, c2g, c2g, w->gtmpB, rB, 0};
+      GemmSection a{c->xmA, c1g, c1g, w->gtmpA, rA, 0, 0}, b{c->xmB, c2g, c2g, w->gtmpB, rB, 0, 0};
       PVW_HIP(launch_gemm_digits(a, b, w->yd, w->sy, c->dt, k, L, l, nv, (size_t)rA * P, (size_t)rB * P, s));
     } else {
       ProfScope ps(c, "mac_rows_multi", s);
@@ -1553,19 +1563,35 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   Workspace* w;
   PVW_TRY(ws_acquire(c, &w));
   hipStream_t s = w->stream;
-  // >= 8 parties: 16 parties per pass on the matrix cores (gemm_digits); fewer: 4 per pass on the VALU
+  // >= 8 parties: the matrix cores (gemm_digits, 16 parties per pass over A^T, everything around it batched
+  // over super-groups of up to 128 parties); fewer: 4 per pass on the VALU
   static int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 8; }();
   const bool use_gemm = gemm_min > 0 && (b - a) >= (u32)gemm_min;
   const u32 group = use_gemm ? 16 : 4;
-  // scratch: A in API layout [k][k][P] | A^T in API layout | A^T tiled or MFMA-tiled | sk,ek of one group | rows of B
+  // super-group: parties whose sampling, NTTs, digit tiles and final tiling are single launches; bounded so
+  // that the digit tiles stay below ~2 GiB
+  u32 sg = group;
+  if (use_gemm) {
+    const size_t per16 = yd_bytes(16, k, L, l);
+    size_t m = ((size_t)2 << 30) / (per16 ? per16 : 1);
+    if (m < 1) m = 1;
+    if (m > 8) m = 8;
+    sg = 16 * (u32)m;
+  }
+  // scratch: A in API layout [k][k][P] | A^T in API layout | A^T tiled or MFMA-tiled | sk,ek of one chunk |
+  //          rows of B for one super-group | gemm intermediate | (gemm) s-hat vectors, sampled e, digit tiles, column sums
   const size_t b_api = ((size_t)k * k * P * 8 + 255) & ~(size_t)255;
   const size_t b_tt = ((use_gemm ? xm_words(k, k, L, l) : c->tiled_words(k)) * 8 + 255) & ~(size_t)255;
-  const u32 chunk = (b - a) < 1024 ? (b - a) : 1024;   // parties whose sk / ek are uploaded together
+  u32 chunk = (b - a) < 1024 ? (b - a) : 1024;         // parties whose sk / ek are uploaded together
+  if (chunk > sg) chunk -= chunk % sg;                  // whole super-groups per chunk
   const size_t b_small = ((size_t)2 * chunk * k * l * 8 + 255) & ~(size_t)255;
-  const size_t b_row = ((size_t)group * k * P * 8 + 255) & ~(size_t)255;
-  const size_t b_tmp = use_gemm ? ((gemm_tmp_words(k, L, l) * 8 + 255) & ~(size_t)255) : 0;
-  int32_t rc = ws_scratch(w, 2 * b_api + b_tt + b_small + b_row + b_tmp);
-  if (rc == PVW_OK && use_gemm) rc = ws_gemm_buffers(c, w);
+  const size_t b_row = ((size_t)sg * k * P * 8 + 255) & ~(size_t)255;
+  const size_t b_tmp = use_gemm ? (((size_t)(sg / 16) * gemm_tmp_words(k, L, l) * 8 + 255) & ~(size_t)255) : 0;
+  const size_t b_vh = use_gemm ? b_row : 0;
+  const size_t b_ec = use_gemm ? (((size_t)sg * k * l * 8 + 255) & ~(size_t)255) : 0;
+  const size_t b_yd = use_gemm ? ((yd_bytes(sg, k, L, l) + 255) & ~(size_t)255) : 0;
+  const size_t b_sy = use_gemm ? ((sy_bytes(sg, L, l) + 255) & ~(size_t)255) : 0;
+  int32_t rc = ws_scratch(w, 2 * b_api + b_tt + b_small + b_row + b_tmp + b_vh + b_ec + b_yd + b_sy);
   if (rc == PVW_OK) {
     char* base = (char*)w->scratch;
     u64* d_api = (u64*)base;
@@ -1574,18 +1600,20 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
     i64* d_small = (i64*)(base + 2 * b_api + b_tt);
     u64* d_row = (u64*)(base + 2 * b_api + b_tt + b_small);
     u64* d_tmp = (u64*)(base + 2 * b_api + b_tt + b_small + b_row);
-    u64* vh = use_gemm ? w->vhat16 : w->rhat;
+    char* gb0 = base + 2 * b_api + b_tt + b_small + b_row + b_tmp;
+    u64* d_vh = (u64*)gb0;
+    i64* d_ec = (i64*)(gb0 + b_vh);
+    signed char* d_yd = (signed char*)(gb0 + b_vh + b_ec);
+    int* d_sy = (int*)(gb0 + b_vh + b_ec + b_yd);
     // A -> API layout -> transpose polynomials (A^T[c][j] = A[j][c]) -> tiled / MFMA-tiled
     bool okk = launch_untile(c->dA, d_api, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
-    for (u32 j = 0; okk && j < k; ++j)
-      okk = hipMemcpy2DAsync(d_apiT + (size_t)j * P, (size_t)k * P * 8, d_api + (size_t)j * k * P, P * 8, P * 8, k,
-                             hipMemcpyDeviceToDevice, s) == hipSuccess;
+    okk = okk && launch_transpose_polys(d_api, d_apiT, k, (u32)P, s) == hipSuccess;
     okk = okk && hipMemsetAsync(d_tt, 0, b_tt, s) == hipSuccess;
     if (use_gemm) okk = okk && launch_mftile(d_apiT, false, d_tt, k, k, L, l, s) == hipSuccess;
     else okk = okk && launch_tile(d_apiT, d_tt, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
     if (!okk) rc = fail(PVW_ERR_INTERNAL, "CRS transpose failed");
-    for (u32 p0 = a; rc == PVW_OK && p0 < b; p0 += group) {
-      const u32 nv = (b - p0) < group ? (b - p0) : group;
+    for (u32 p0 = a; rc == PVW_OK && p0 < b; p0 += sg) {
+      const u32 nv = (b - p0) < sg ? (b - p0) : sg;
       const u32 in_chunk = (p0 - a) % chunk;                       // position inside the uploaded chunk
       if (in_chunk == 0) {
         const u32 cn = (b - p0) < chunk ? (b - p0) : chunk;
@@ -1598,28 +1626,37 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
       }
       ProfScope ps(c, "keygen", s);
       bool ok2 = true;
-      for (u32 v0 = 0; ok2 && v0 < nv; v0 += 16) {                 // s-hat_p and NTT(e_p), up to 16 parties per launch
-        const u32 cnt = (nv - v0) < 16 ? (nv - v0) : 16;
+      if (use_gemm) {
+        // e_p (public_key.rs:128-132): sampled or explicit coefficients -> NTT form in the row buffer [nv][k][P]
+        const i64* e_src = ek ? d_small + (size_t)(chunk + in_chunk) * k * l : d_ec;
+        if (!ek) {
+          SampleJob je{}, z{};
+          je.kind = SAMPLE_UNIFORM; je.domain = DOM_EKEY; je.index0 = p0 * k; je.count = nv * k; je.bound = c->b1;
+          ok2 = launch_sample(d_ec, make_key(seed), l, je, z, z, s) == hipSuccess;
+        }
+        ok2 = ok2 && launch_prep(e_src, nullptr, d_row, P, l, nv * k, true, c->dt, L, l, s) == hipSuccess;
+        // s-hat_p (secret_key.rs:98-112) in the vector layout [party][limb][j][slot]
+        ok2 = ok2 && launch_prep(d_small + (size_t)in_chunk * k * l, nullptr, d_vh, l, (size_t)k * l, nv * k, true, c->dt, L, l, s,
+                                 k, (size_t)k * P) == hipSuccess;
+        ok2 = ok2 && launch_vec_digits(d_vh, (size_t)k * P, d_yd, d_sy, nv, k, L, l, c->dt, s) == hipSuccess;
+        // all batches of 16 parties in one launch (crs.rs:152-168): they share A^T through L2
+        GemmSection ga{d_tt, d_row, d_row, d_tmp, k, 0, 0}, gb{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        ok2 = ok2 && launch_gemm_digits(ga, gb, d_yd, d_sy, c->dt, k, L, l, nv, (size_t)k * P, 0, s) == hipSuccess;
+      } else {
+        u64* vh = w->rhat;
         PrologueBatch pb{};
         if (seed) pb.key[0] = make_key(seed);
-        for (u32 x = 0; x < cnt; ++x) {
-          const u32 v = v0 + x;
-          PrologueJob& js = pb.job[2 * x];
-          PrologueJob& je = pb.job[2 * x + 1];
+        for (u32 v = 0; v < nv; ++v) {
+          PrologueJob& js = pb.job[2 * v];
+          PrologueJob& je = pb.job[2 * v + 1];
           js.sj.count = k; js.explicit_coeffs = d_small + (size_t)(in_chunk + v) * k * l;    // secret_key.rs:98-112
           js.out = vh + (size_t)v * k * P; js.stride_poly = l; js.stride_limb = (size_t)k * l;
           je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = (p0 + v) * k; je.sj.count = k; je.sj.bound = c->b1;  // public_key.rs:128-132
           if (ek) je.explicit_coeffs = d_small + (size_t)(chunk + in_chunk + v) * k * l;
           je.out = d_row + (size_t)v * k * P; je.stride_poly = P; je.stride_limb = l;
         }
-        pb.njobs = 2 * cnt;
+        pb.njobs = 2 * nv;
         ok2 = launch_prologue(pb, c->dt, L, l, s) == hipSuccess;
-      }
-      if (use_gemm) {                                                                        // crs.rs:152-168
-        ok2 = ok2 && launch_vec_digits(vh, (size_t)k * P, w->yd, w->sy, nv, k, L, l, c->dt, s) == hipSuccess;
-        GemmSection ga{d_tt, d_row, d_row, d_tmp, k, 0}, gb{nullptr, nullptr, nullptr, nullptr, 0, 0};
-        ok2 = ok2 && launch_gemm_digits(ga, gb, w->yd, w->sy, c->dt, k, L, l, nv, (size_t)k * P, 0, s) == hipSuccess;
-      } else {
         MacSection sa{d_tt, d_row, d_row, k, 0}, sb{nullptr, nullptr, nullptr, 0, 0};
         MultiVec mv{vh, (size_t)k * P, (size_t)k * P, 0, nv};
         ok2 = ok2 && launch_mac_rows_multi(sa, sb, mv, c->dt, k, L, l, s) == hipSuccess;

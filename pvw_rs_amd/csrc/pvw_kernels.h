@@ -50,9 +50,12 @@ struct MacSection {
 // c1 (section a: A-hat rows) and c2 (section b: B-hat rows) in a single launch
 hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat,
                            const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s);
+// group != 0: polynomial p goes to out + (p / group) * stride_group + (p % group) * stride_poly
 hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t stride_poly,
                        size_t stride_limb, u32 count, bool do_ntt, const DevTables& t, u32 L,
-                       u32 ell, hipStream_t s);
+                       u32 ell, hipStream_t s, u32 group = 0, size_t stride_group = 0);
+// dst[c][j] = src[j][c] for a k x k matrix of polynomials of `words` u64 each
+hipError_t launch_transpose_polys(const u64* src, u64* dst, u32 k, u32 words, hipStream_t s);
 hipError_t launch_ntt(u64* polys, size_t count, bool inverse, const DevTables& t, u32 L, u32 ell,
                       hipStream_t s);
 hipError_t launch_tile(const u64* src, u64* M, u32 rows, u32 row0_tiled, u32 k, u32 L, u32 ell,
@@ -116,6 +119,7 @@ struct GemmSection {
   u64* tmp;            // intermediate [limb][slot][16 vectors][rows padded to whole workgroups]
   u32 nrows;
   u32 rt_groups;       // filled in by the launcher
+  size_t tmp_bstride;  // words of `tmp` per batch of 16 vectors (filled in by the launcher)
 };
 inline size_t gemm_tmp_words(u32 rows, u32 L, u32 ell) {
   return (size_t)L * ell * 16 * (((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * PVW_GEMM_ROWS_PER_WG);
@@ -129,6 +133,8 @@ inline size_t sy_bytes(u32 nv, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) *
 hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s);
 hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
                              const DevTables& t, hipStream_t s);
+// nv may exceed 16: batches of 16 vectors then run as extra workgroups of ONE launch (adjacent in dispatch
+// order, so they share the streamed matrix tiles through L2); tmp must hold ceil(nv/16) batches.
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
                               hipStream_t s);

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64) void prep_kernel(const i64* __restrict__ coeffs
                                                    const u64* __restrict__ scalars,
                                                    u64* __restrict__ out, size_t stride_poly,
                                                    size_t stride_limb, u32 count, u32 L,
-                                                   u32 do_ntt, DevTables t) {
+                                                   u32 do_ntt, DevTables t, u32 group, size_t stride_group) {
   const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= count * L) return;
   const u32 p = tid / L, limb = tid % L;
@@ -426,10 +426,23 @@ __global__ __launch_bounds__(64) void prep_kernel(const i64* __restrict__ coeffs
 #pragma unroll
     for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod_shoup(mr, g[s], gp[s], m.q), m.q);
   }
-  u64* o = out + (size_t)p * stride_poly + (size_t)limb * stride_limb;
+  u64* o = out + (group ? (size_t)(p / group) * stride_group + (size_t)(p % group) * stride_poly : (size_t)p * stride_poly) +
+           (size_t)limb * stride_limb;
 #pragma unroll
   for (int s = 0; s < ELL; s += 2)
     *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
+}
+
+// dst[c][j] = src[j][c] over a k x k matrix of polynomials (`words` u64 each): key generation walks the
+// CRS by columns (crs.rs:152-168)
+__global__ __launch_bounds__(256) void transpose_polys_kernel(const u64* __restrict__ src, u64* __restrict__ dst,
+                                                               u32 k, u32 words) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)k * k * words) return;
+  const u32 x = idx % words;
+  const size_t pj = idx / words;
+  const u32 j = pj / k, c = pj % k;
+  dst[((size_t)c * k + j) * words + x] = src[idx];
 }
 
 // in-place change_representation on [count][L][l] polynomials
@@ -1604,22 +1617,36 @@ __device__ __forceinline__ int xor_lane_dpp(int v, int d) {
   return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, false);                // quad_perm [3,2,1,0]
 }
 
-template <int ELL, int NVG, int RPW>
+#ifndef PVW_GEMM_ABLATE
+#define PVW_GEMM_ABLATE 0
+#endif
+#define PVW_ABL(bit) ((PVW_GEMM_ABLATE & (bit)) != 0)
+template <int ELL, int NVG, int RPW, int NCH = 0>
 __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
                                                            const int* __restrict__ SY, const Mod* __restrict__ mods,
-                                                           u32 k, u32 L, u32 nv, u32 nv_pad) {
+                                                           u32 k, u32 L, u32 nv_total, u32 nv_pad, u32 dbg, u32 vbn,
+                                                           size_t yd_b16, size_t sy_b16) {
+  // dbg (PVW_GEMM_DEBUG, timing experiments only, results wrong): 1 = no K loop, 2 = no epilogue;
+  // compile-time ablations -DPVW_GEMM_ABLATE=bits: 8 = no A loads, 16 = no B loads, 32 = no MFMA
   // block = (limb, slot, group of 4*RPW row tiles); the 4 waves share the vector-digit tiles through
   // LDS (CJ j-blocks at a time); each wave owns RPW row tiles of 32 rows and streams their raw u64 tiles.
   constexpr int CJ = 8;                                    // j-blocks per staged chunk (32 MFMAs per wave per barrier)
   constexpr int BSH = NVG * CJ * 64 / 256;                 // 16-byte B elements each thread stages per chunk
   __shared__ v4i32 bl[2][NVG * CJ * 64];                   // two chunks of NVG*CJ KiB
-  const u32 JB = (k + 3) / 4;
+  const u32 JB = (dbg & 1) ? 0 : (k + 3) / 4;
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 rtg_total = sa.rt_groups + sb.rt_groups;
   // XCD-aware order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of
   // block ids -- workgroups that share the vector-digit tiles of one (limb, slot) then hit in L2
   u32 bid = blockIdx.x;
   if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  // batches of 16 vectors are the fastest-varying part of the block id: the vbn workgroups that stream the
+  // same matrix tiles sit next to each other on one XCD and share them through its L2
+  const u32 vb = bid % vbn;
+  bid /= vbn;
+  const u32 nv = (nv_total - 16 * vb) < 16 ? (nv_total - 16 * vb) : 16;
+  YD += vb * yd_b16;
+  SY += vb * sy_b16;
   const u32 ls = bid / rtg_total, rtg = bid % rtg_total;
   const u32 limb = ls / ELL, slot = ls % ELL;
   const bool in_a = rtg < sa.rt_groups;
@@ -1644,56 +1671,89 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
   const v4i32 zero4 = (v4i32){0, 0, 0, 0};
   // software pipeline over chunks of CJ j-blocks: the A tiles and this thread's share of the B tiles
   // of chunk c+1 are in flight (registers) while chunk c is multiplied out of LDS
+  // Every load below is UNCONDITIONAL (clamped index, select afterwards): a load inside a branch makes hipcc
+  // fall back to s_waitcnt vmcnt(0) at the loop header, which drains the whole prefetch pipeline on every
+  // chunk.  Rows past the section's end read the zeroed padding of XM (their results are never stored) and
+  // tiles past JB re-read the last tile against zero B digits.
+  const u32 jlast = JB ? JB - 1 : 0;
   auto fetch_a = [&](u32 jc, v4i32 (&an)[RPW][CJ]) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r)
 #pragma unroll
-      for (int u = 0; u < CJ; ++u)
-        an[r][u] = (live[r] && jc + u < JB) ? __builtin_nontemporal_load(ap[r] + (size_t)(jc + u) * 64) : flip;
+      for (int u = 0; u < CJ; ++u) {
+        const u32 j = (jc + u) < JB ? (jc + u) : jlast;
+        an[r][u] = PVW_ABL(8) ? flip : __builtin_nontemporal_load(ap[r] + (size_t)j * 64);
+      }
   };
   auto fetch_b = [&](u32 jc, v4i32 (&bn)[BSH]) {
 #pragma unroll
     for (int x = 0; x < BSH; ++x) {
       const u32 e = threadIdx.x + 256 * x;                  // element of the [NVG][CJ][64] chunk
       const u32 g = e / (CJ * 64), rem = e % (CJ * 64), u = rem / 64;
-      bn[x] = (jc + u < JB) ? ybase[((((size_t)g * L + limb) * ELL + slot) * JB + jc) * 64 + rem] : zero4;
+      const bool in = (jc + u) < JB;
+      const u32 jb = in ? (jc + u) : jlast;
+      const v4i32 val = PVW_ABL(16) ? zero4 : ybase[((((size_t)g * L + limb) * ELL + slot) * JB + jb) * 64 + (rem & 63)];
+      bn[x] = in ? val : zero4;
     }
   };
-  // A tiles are prefetched TWO chunks ahead (register ring a -> an -> an2), B one chunk ahead (bn -> LDS).
-  // (A ring rotated by renaming -- the loop unrolled by three -- measured slower than these moves.)
-  v4i32 a[RPW][CJ], an[RPW][CJ], an2[RPW][CJ], bn[BSH];
+  // A tiles are prefetched TWO chunks ahead through three register sets used in rotation, B one chunk ahead
+  // (bn -> LDS).  NCH != 0: the chunk loop is fully unrolled (JB == NCH * CJ), so the rotation is plain
+  // renaming and hipcc can count the outstanding loads exactly; around a loop back-edge it falls back to
+  // s_waitcnt vmcnt(0), which cuts the lead to one chunk (the NCH == 0 form, kept for other k).
+  v4i32 aset[3][RPW][CJ], bn[BSH];
   fetch_b(0, bn);
-  fetch_a(0, a);
-  fetch_a(CJ, an);
+  fetch_a(0, aset[0]);
+  fetch_a(CJ, aset[1]);
 #pragma unroll
   for (int x = 0; x < BSH; ++x) bl[0][threadIdx.x + 256 * x] = bn[x];
   __syncthreads();
-  u32 cur = 0;
-  for (u32 jc = 0; jc < JB; jc += CJ) {
-    const bool more = jc + CJ < JB;
-    if (more) fetch_b(jc + CJ, bn);
-    fetch_a(jc + 2 * CJ, an2);                              // past the end: synthesised zero tiles, no memory access
+  // one chunk: issue the loads for later chunks, multiply chunk jc out of `ac` and bl[cur], stage B of chunk jc+CJ
+  auto step = [&](u32 jc, u32 cur, v4i32 (&ac)[RPW][CJ], v4i32 (&aload)[RPW][CJ], bool load_a) {
+    fetch_b(jc + CJ, bn);                                   // past the end: clamped re-reads (cache hits), unused
+    if (load_a) fetch_a(jc + 2 * CJ, aload);
+    // B fragments of step u+1 are read from LDS while the MFMAs of step u run (two register sets); the
+    // sched_barriers keep hipcc from sinking each read next to its use, which exposes the LDS latency
+    // before every other MFMA
+    v4i32 bf[2][NVG];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
+    for (int g = 0; g < NVG; ++g) bf[0][g] = bl[cur][g * (CJ * 64) + lane];
 #pragma unroll
-      for (int u = 0; u < CJ; ++u) {
-        const v4i32 ax = a[r][u] ^ flip;                    // tiles past the end were fetched as `flip`: zero bytes here
+    for (int u = 0; u < CJ; ++u) {
+      if (u + 1 < CJ) {
 #pragma unroll
-        for (int g = 0; g < NVG; ++g)
-          acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ax, bl[cur][g * (CJ * 64) + u * 64 + lane], acc[r][g], 0, 0, 0);
+        for (int g = 0; g < NVG; ++g) bf[(u + 1) & 1][g] = bl[cur][g * (CJ * 64) + (u + 1) * 64 + lane];
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const v4i32 ax = ac[r][u] ^ flip;
+#pragma unroll
+        for (int g = 0; g < NVG; ++g) {
+          if (PVW_ABL(32)) acc[r][g][0] += ax[0] ^ bf[u & 1][g][0];   // timing experiment: no MFMA
+          else acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ax, bf[u & 1][g], acc[r][g], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) {
-      // the other buffer was last read in the previous iteration, which every wave left through the barrier below
+    // the other buffer was last read in the previous step, which every wave left through the barrier below
 #pragma unroll
-      for (int x = 0; x < BSH; ++x) bl[cur ^ 1][threadIdx.x + 256 * x] = bn[x];
-    }
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-      for (int u = 0; u < CJ; ++u) { a[r][u] = an[r][u]; an[r][u] = an2[r][u]; }
+    for (int x = 0; x < BSH; ++x) bl[cur ^ 1][threadIdx.x + 256 * x] = bn[x];
     __syncthreads();
-    cur ^= 1;
+  };
+  if constexpr (NCH != 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) step(c * CJ, c & 1, aset[c % 3], aset[(c + 2) % 3], c + 2 < NCH);
+  } else {
+    // rotation by register moves (each move waits for the loads it copies: one chunk of lead)
+    u32 cur = 0;
+    for (u32 jc = 0; jc < JB; jc += CJ) {
+      step(jc, cur, aset[0], aset[2], true);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int u = 0; u < CJ; ++u) { aset[0][r][u] = aset[1][r][u]; aset[1][r][u] = aset[2][r][u]; }
+      cur ^= 1;
+    }
   }
   // recombine: out[m][v] = sum_b (C[m][(v,b)] + 128*SY[(v,b)]) 2^(8b)  mod q.
   // Lane (v, b) holds column b of 16 rows; an 8x8 transpose across the 8 lanes of a vector (three
@@ -1701,6 +1761,17 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
   // register file, which it then weighs, reduces and stores.
   const Mod m = mods[limb];
   const u32 h = lane >> 5, col = lane & 31, b = col & 7, v4 = col >> 3;
+  if (dbg & 2) {
+    int keep = 0;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int g = 0; g < NVG; ++g)
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) keep ^= acc[r][g][tt];
+    if (keep == 0x7fffffff && k == 0xffffffffu) sec.tmp[0] = 1;
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     if (!live[r]) continue;
@@ -1749,7 +1820,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
           u64 res = reduce128(lo, hi, m);
           if (neg && res) res = m.q - res;
           // intermediate [limb][slot][v][row]: the 16 lanes of one vector write 16 consecutive rows
-          sec.tmp[(((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res;
+          sec.tmp[vb * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res;
         }
       }
     }
@@ -1766,7 +1837,7 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
   const u32 row0 = rb * 32;
   for (u32 e = threadIdx.x; e < 32 * ELL; e += 256) {
     const u32 row = e & 31, slot = e >> 5;
-    tile[slot][row] = sec.tmp[(((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row0 + row];
+    tile[slot][row] = sec.tmp[(v >> 4) * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + (nv_pad == 16 ? (v & 15) : v)) * rows_pad + row0 + row];
   }
   __syncthreads();
   const u64 q = mods[limb].q;
@@ -1874,11 +1945,18 @@ hipError_t launch_mac_rows_multi(const MacSection& a, const MacSection& b, const
 
 hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t stride_poly,
                        size_t stride_limb, u32 count, bool do_ntt, const DevTables& t, u32 L,
-                       u32 ell, hipStream_t s) {
+                       u32 ell, hipStream_t s, u32 group, size_t stride_group) {
   if (count == 0) return hipSuccess;
   const u32 threads = count * L;
   PVW_DISPATCH_ELL(ell, prep_kernel<E><<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(coeffs, scalars, out, stride_poly, stride_limb, count, L,
-                                            do_ntt ? 1u : 0u, t));
+                                            do_ntt ? 1u : 0u, t, group, stride_group));
+  return hipGetLastError();
+}
+
+hipError_t launch_transpose_polys(const u64* src, u64* dst, u32 k, u32 words, hipStream_t s) {
+  const size_t total = (size_t)k * k * words;
+  if (total == 0) return hipSuccess;
+  transpose_polys_kernel<<<dim3((u32)((total + 255) / 256)), dim3(256), 0, s>>>(src, dst, k, words);
   return hipGetLastError();
 }
 
@@ -2092,14 +2170,24 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   sb.rt_groups = (sb.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
   const u32 blocks = (sa.rt_groups + sb.rt_groups) * L * ell;
   if (blocks == 0 || nv == 0) return hipSuccess;
-  const u32 NVG = (nv + 3) / 4;
+  const u32 vbn = (nv + 15) / 16;
+  const u32 NVG = vbn > 1 ? 4 : (nv + 3) / 4;
   const u32 nv_pad = NVG * 4;
-#define PVW_GEMM_LAUNCH(G) PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad))
-  switch (NVG) {
-    case 1: PVW_GEMM_LAUNCH(1); break;
-    case 2: PVW_GEMM_LAUNCH(2); break;
-    case 3: PVW_GEMM_LAUNCH(3); break;
-    case 4: PVW_GEMM_LAUNCH(4); break;
+  sa.tmp_bstride = (size_t)L * ell * 16 * sa.rt_groups * PVW_GEMM_ROWS_PER_WG;
+  sb.tmp_bstride = (size_t)L * ell * 16 * sb.rt_groups * PVW_GEMM_ROWS_PER_WG;
+  const size_t yd_b16 = yd_bytes(16, k, L, ell), sy_b16 = sy_bytes(16, L, ell) / sizeof(int);
+  u32 dbg = 0;
+  if (const char* e = getenv("PVW_GEMM_DEBUG")) dbg = (u32)atoi(e);
+#define PVW_GEMM_LAUNCH(G, N) PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16))
+  // fully unrolled chunk loops for the BASELINE geometries (k = 256: 8 chunks of 8 j-blocks, k = 512: 16), full vector groups
+  static int unroll_ok = [] { const char* e = getenv("PVW_GEMM_UNROLL"); return e ? atoi(e) : 1; }();
+  if (NVG == 4 && unroll_ok && !(dbg & 1) && k == 256) { PVW_GEMM_LAUNCH(4, 8); }
+  else if (NVG == 4 && unroll_ok && !(dbg & 1) && k == 512) { PVW_GEMM_LAUNCH(4, 16); }
+  else switch (NVG) {
+    case 1: PVW_GEMM_LAUNCH(1, 0); break;
+    case 2: PVW_GEMM_LAUNCH(2, 0); break;
+    case 3: PVW_GEMM_LAUNCH(3, 0); break;
+    case 4: PVW_GEMM_LAUNCH(4, 0); break;
     default: return hipErrorInvalidValue;
   }
 #undef PVW_GEMM_LAUNCH
