@@ -73,23 +73,44 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
 
   for (u32 jc = j0; jc < j1; jc += JC) {
     const u32 cnt = (j1 - jc) < (u32)JC ? (j1 - jc) : (u32)JC;
-    __builtin_amdgcn_wave_barrier();
-    for (u32 idx = lane; idx < cnt * HALF; idx += 64) lw[idx] = rp[(size_t)gmap(jc + idx / HALF) * HALF + idx % HALF];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    u32 jj = 0;
     auto ld = [&](u32 tile) -> v2u64 {
       const v2u64* p = Mp + (size_t)gmap(jc + tile) * 64;
       if constexpr (NT) return __builtin_nontemporal_load(p);
       else return *p;
     };
+    __builtin_amdgcn_wave_barrier();
+    // all of this lane's r-hat elements are requested before the first is awaited (a load per loop trip
+    // would pay one L2 round trip each); indices past the chunk's end are clamped and not stored
+    constexpr int RN = JC * HALF / 64;
+    v2u64 rv[RN];
+#pragma unroll
+    for (int x = 0; x < RN; ++x) {
+      const u32 idx = lane + 64 * x;
+      const u32 ic = idx < cnt * HALF ? idx : 0;
+      rv[x] = rp[(size_t)gmap(jc + ic / HALF) * HALF + ic % HALF];
+    }
+    // (DBUF) the chunk's first U matrix tiles are requested behind them, before the wave waits for r-hat
+    v2u64 x[DBUF ? U : 1];
+    const bool full = DBUF && cnt >= U;
     if constexpr (DBUF) {
-      // two register buffers: the next U tiles are in flight while the current U are consumed
-      if (cnt >= U) {
-        v2u64 x[U], xn[U];
+      if (full) {
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u] = ld(u);
+      }
+    }
+#pragma unroll
+    for (int xx = 0; xx < RN; ++xx) {
+      const u32 idx = lane + 64 * xx;
+      if (idx < cnt * HALF) lw[idx] = rv[xx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    u32 jj = 0;
+    if constexpr (DBUF) {
+      // two register buffers: the next U tiles are in flight while the current U are consumed
+      if (full) {
+        v2u64 xn[U];
         for (; jj + 2 * U <= cnt; jj += U) {
 #pragma unroll
           for (int u = 0; u < U; ++u) xn[u] = ld(jj + U + u);
