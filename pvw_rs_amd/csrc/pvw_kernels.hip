@@ -1575,7 +1575,16 @@ __global__ __launch_bounds__(256) void mftile_kernel(const u64* __restrict__ src
 // One wave per (v, limb, slot); lane = j-block: each lane turns 4 consecutive j into the 8 shifted
 // copies y*2^(8a) mod q, writes their balanced digits as 16 16-byte runs, and the column sums are
 // reduced across the wave (no atomics).
-template <int ELL>
+// 4x4 byte transpose of four dwords (y_i byte j = x_j byte i) with v_perm_b32
+__device__ __forceinline__ void transpose4x4_bytes(u32 x0, u32 x1, u32 x2, u32 x3, u32& y0, u32& y1, u32& y2, u32& y3) {
+  const u32 t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+  const u32 t2 = __builtin_amdgcn_perm(x3, x2, 0x05010400u), t3 = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+  y0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+  y1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+  y2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+  y3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+template <int ELL, bool STAGE>
 __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ vhat, size_t vstride,
                                                          signed char* __restrict__ YD, int* __restrict__ SY,
                                                          u32 nv, u32 k, u32 L, DevTables t) {
@@ -1590,34 +1599,67 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
   const u64* y = vhat + (size_t)v * vstride + (size_t)limb * k * ELL + slot;
   signed char* tiles = YD + (((size_t)vg * L + limb) * ELL + slot) * (size_t)JB * 1024;
   int colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (u32 jb = lane; jb < JB; jb += 64) {
-    // digit[b][kappa], kappa = 8*jj + a  (32 bytes per digit column b)
-    union { signed char c[8][32]; v4i32 q[8][2]; } dg;
+  __shared__ v4i32 st[STAGE ? 64 * 16 : 1];                     // [tile of this pass][piece], 16 KiB
+  const u32 jb_end = STAGE ? ((JB + 63) & ~63u) : JB;           // STAGE: whole passes, every lane takes part in the staging
+  for (u32 jb = lane; jb < jb_end; jb += 64) {
+    // digit[b][kappa], kappa = 8*jj + a  (32 bytes per digit column b = four u64, one per jj)
+    union { u64 d[8][4]; v4i32 q[8][2]; } dg;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const u32 j = 4 * jb + jj;
       u64 cur = j < k ? y[(size_t)j * ELL] : 0;
+      // the 8 balanced base-256 digits of w < 2^62 are the bytes of (w + 0x80..80) with their top bits
+      // flipped: adding 128 to every byte position propagates exactly the carries of "digit > 127"
+      const u64 C = 0x8080808080808080ULL;
+      u32 rl[8], rh[8];                                          // rows a: digits b = 0..3 | 4..7
 #pragma unroll
       for (int a = 0; a < 8; ++a) {
-        u64 w = cur;
-        int carry = 0;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          int d = (int)(w & 0xff) + carry;
-          w >>= 8;
-          carry = d > 127;
-          d -= carry << 8;
-          dg.c[b][8 * jj + a] = (signed char)d;
-          colsum[b] += d;
-        }
+        const u64 dgt = (cur + C) ^ C;
+        rl[a] = (u32)dgt;
+        rh[a] = (u32)(dgt >> 32);
         cur = mulmod_shoup(cur, 256, w256p, m.q);
       }
-    }
-    signed char* tile = tiles + (size_t)jb * 1024;
+      // 8x8 byte transpose: column b gets the bytes a = 0..7
+      u32 cl[8], ch[8];
+      transpose4x4_bytes(rl[0], rl[1], rl[2], rl[3], cl[0], cl[1], cl[2], cl[3]);
+      transpose4x4_bytes(rl[4], rl[5], rl[6], rl[7], ch[0], ch[1], ch[2], ch[3]);
+      transpose4x4_bytes(rh[0], rh[1], rh[2], rh[3], cl[4], cl[5], cl[6], cl[7]);
+      transpose4x4_bytes(rh[4], rh[5], rh[6], rh[7], ch[4], ch[5], ch[6], ch[7]);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      *reinterpret_cast<v4i32*>(tile + (size_t)(0 * 32 + v4 * 8 + b) * 16) = dg.q[b][0];   // h = 0: kappa 0..15
-      *reinterpret_cast<v4i32*>(tile + (size_t)(1 * 32 + v4 * 8 + b) * 16) = dg.q[b][1];   // h = 1: kappa 16..31
+      for (int b = 0; b < 8; ++b) {
+        dg.d[b][jj] = ((u64)ch[b] << 32) | cl[b];
+        colsum[b] = __builtin_amdgcn_sdot4((int)cl[b], 0x01010101, colsum[b], false);
+        colsum[b] = __builtin_amdgcn_sdot4((int)ch[b], 0x01010101, colsum[b], false);
+      }
+    }
+    if constexpr (STAGE) {
+      // this lane's 16 runs of 16 bytes (piece = 8 h + b) go through LDS so that every global store
+      // instruction writes whole 128-byte lines (lanes 8x..8x+7 = the 8 digit columns of one (tile, h)).
+      // The piece index is XORed with the tile index so that neither side has bank conflicts.
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        st[lane * 16 + ((0 * 8 + b) ^ (lane & 15))] = dg.q[b][0];   // h = 0: kappa 0..15
+        st[lane * 16 + ((1 * 8 + b) ^ (lane & 15))] = dg.q[b][1];   // h = 1: kappa 16..31
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const u32 jb0 = jb - lane;                                   // first tile of this pass
+#pragma unroll 4
+      for (u32 it = 0; it < 16; ++it) {
+        const u32 tl = it * 4 + (lane >> 4), piece = lane & 15;
+        const v4i32 val = st[tl * 16 + (piece ^ (tl & 15))];
+        const u32 hh = piece >> 3, bb = piece & 7;
+        if (jb0 + tl < JB)
+          *reinterpret_cast<v4i32*>(tiles + (size_t)(jb0 + tl) * 1024 + (size_t)(hh * 32 + v4 * 8 + bb) * 16) = val;
+      }
+    } else {
+      signed char* tile = tiles + (size_t)jb * 1024;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        *reinterpret_cast<v4i32*>(tile + (size_t)(0 * 32 + v4 * 8 + b) * 16) = dg.q[b][0];   // h = 0: kappa 0..15
+        *reinterpret_cast<v4i32*>(tile + (size_t)(1 * 32 + v4 * 8 + b) * 16) = dg.q[b][1];   // h = 1: kappa 16..31
+      }
     }
   }
 #pragma unroll
@@ -2179,7 +2221,10 @@ hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, i
     e = hipMemsetAsync(SY + (size_t)(NVG - 1) * L * ell * 32, 0, (size_t)L * ell * 32 * sizeof(int), s);
     if (e != hipSuccess) return e;
   }
-  PVW_DISPATCH_ELL(ell, vec_digits_kernel<E><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t));
+  // default: stores staged through LDS (whole 128-byte lines per instruction, 16 KiB per wave); PVW_VEC_DIGITS_STAGE=0: direct
+  static int stage = [] { const char* e = getenv("PVW_VEC_DIGITS_STAGE"); return e ? atoi(e) : 1; }();
+  if (stage) { PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, true><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t)); }
+  else { PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, false><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t)); }
   return hipGetLastError();
 }
 
