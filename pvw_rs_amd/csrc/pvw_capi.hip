@@ -299,6 +299,12 @@ static int32_t upload_tables(pvw_ctx* c) {
     return at;
   };
   c->dt.mods = (const Mod*)put(c->mods.data(), L * sizeof(Mod));
+  c->dt.min_q_bits = 64;
+  for (u32 i = 0; i < L; ++i) {
+    u32 bits = 0;
+    for (u64 q = c->mods[i].q; q; q >>= 1) ++bits;
+    if (bits < c->dt.min_q_bits) c->dt.min_q_bits = bits;
+  }
   c->dt.tw = (const u64*)put(c->tw.data(), L * l * 8);
   c->dt.itw = (const u64*)put(c->itw.data(), L * l * 8);
   c->dt.ghat = (const u64*)put(c->ghat.data(), L * l * 8);

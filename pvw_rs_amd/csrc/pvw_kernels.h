@@ -24,6 +24,7 @@ struct DevTables {
   const u64* linvp;
   const u64* ghatp;
   const u64* gpowp;
+  u32 min_q_bits;    // bit length of the smallest modulus (kernels with a fast path for wide moduli test it)
 };
 
 enum { SAMPLE_CBD = 0, SAMPLE_UNIFORM = 1 };

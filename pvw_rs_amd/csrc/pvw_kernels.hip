@@ -1567,7 +1567,7 @@ __global__ __launch_bounds__(256) void mftile_kernel(const u64* __restrict__ src
 #pragma unroll
   for (int sl = 0; sl < ELL; ++sl) {
     const size_t tile = (((size_t)limb * ELL + sl) * RT + rt) * JB + jb;
-    XM[tile * 128 + (h * 32 + m) * 2 + e] = p[sl];
+    XM[tile * 128 + (h * 32 + m) * 2 + e] = p[sl] ^ 0x8080808080808080ULL;   // bytes stored signed-offset (x - 128): the i8 MFMA operand as is
   }
 }
 
@@ -1684,7 +1684,7 @@ __device__ __forceinline__ int xor_lane_dpp(int v, int d) {
 #define PVW_GEMM_ABLATE 0
 #endif
 #define PVW_ABL(bit) ((PVW_GEMM_ABLATE & (bit)) != 0)
-template <int ELL, int NVG, int RPW, int NCH = 0>
+template <int ELL, int NVG, int RPW, int NCH = 0, bool FASTQ = false>
 __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
                                                            const int* __restrict__ SY, const Mod* __restrict__ mods,
                                                            u32 k, u32 L, u32 nv_total, u32 nv_pad, u32 dbg, u32 vbn,
@@ -1696,7 +1696,8 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
   constexpr int CJ = 8;                                    // j-blocks per staged chunk (32 MFMAs per wave per barrier)
   constexpr int BSH = NVG * CJ * 64 / 256;                 // 16-byte B elements each thread stages per chunk
   __shared__ v4i32 bl[2][NVG * CJ * 64];                   // two chunks of NVG*CJ KiB
-  const u32 JB = (dbg & 1) ? 0 : (k + 3) / 4;
+  // NCH != 0: the launcher guarantees k == 4 * NCH * CJ, so every bounds test below folds away
+  const u32 JB = NCH ? (u32)(NCH * CJ) : ((dbg & 1) ? 0 : (k + 3) / 4);
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 rtg_total = sa.rt_groups + sb.rt_groups;
   // XCD-aware order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of
@@ -1730,7 +1731,6 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
   for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int g = 0; g < NVG; ++g) acc[r][g] = (v16i32){};
-  const v4i32 flip = (v4i32){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
   const v4i32 zero4 = (v4i32){0, 0, 0, 0};
   // software pipeline over chunks of CJ j-blocks: the A tiles and this thread's share of the B tiles
   // of chunk c+1 are in flight (registers) while chunk c is multiplied out of LDS
@@ -1745,7 +1745,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 #pragma unroll
       for (int u = 0; u < CJ; ++u) {
         const u32 j = (jc + u) < JB ? (jc + u) : jlast;
-        an[r][u] = PVW_ABL(8) ? flip : __builtin_nontemporal_load(ap[r] + (size_t)j * 64);
+        an[r][u] = PVW_ABL(8) ? zero4 : __builtin_nontemporal_load(ap[r] + (size_t)j * 64);
       }
   };
   auto fetch_b = [&](u32 jc, v4i32 (&bn)[BSH]) {
@@ -1789,7 +1789,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
-        const v4i32 ax = ac[r][u] ^ flip;
+        const v4i32 ax = ac[r][u];                          // XM holds the bytes already offset by -128
 #pragma unroll
         for (int g = 0; g < NVG; ++g) {
           if (PVW_ABL(32)) acc[r][g][0] += ax[0] ^ bf[u & 1][g][0];   // timing experiment: no MFMA
@@ -1819,11 +1819,11 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
     }
   }
   // recombine: out[m][v] = sum_b (C[m][(v,b)] + 128*SY[(v,b)]) 2^(8b)  mod q.
-  // Lane (v, b) holds column b of 16 rows; an 8x8 transpose across the 8 lanes of a vector (three
-  // exchange steps on raw i32 values) gives lane b all eight digits of rows `b` and `b+8` of its
-  // register file, which it then weighs, reduces and stores.
+  // Lane (v, b) holds column b of 16 rows; three exchange steps across the 8 lanes of a vector leave lane b
+  // with the complete sums of rows `b` and `b+8` of its register file, which it reduces and stores.
   const Mod m = mods[limb];
   const u32 h = lane >> 5, col = lane & 31, b = col & 7, v4 = col >> 3;
+  const double inv32 = 4294967296.0 / (double)m.q;           // FASTQ: every modulus is wider than 54 bits
   if (dbg & 2) {
     int keep = 0;
 #pragma unroll
@@ -1844,47 +1844,70 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
       const int sy128 = 128 * SY[(((size_t)g * L + limb) * ELL + slot) * 32 + col];
       int x[16];
 #pragma unroll
-      for (int tt = 0; tt < 16; ++tt) x[tt] = acc[r][g][tt] + sy128;          // |.| < 2^27
+      for (int tt = 0; tt < 16; ++tt) x[tt] = acc[r][g][tt] + sy128;          // |.| < 2^26
+      // Weighted butterfly over the 8 lanes (b = 0..7) of one vector: at step d the lane with bit d of b
+      // clear keeps the registers whose index has bit d clear and adds its partner's copy times 2^(8d); the
+      // other lane keeps the rest.  After d = 1, 2 each lane holds 4 sums of four digits (< 2^52); the last
+      // exchange pairs the low half (digits 0-3) with the high half (digits 4-7) of registers b and b + 8.
+      // (the empty asm pins values in registers: without it hipcc folds the selects into a runtime register
+      // index and expands every access into a 16-way v_cndmask chain)
+      const bool up1 = (b & 1) != 0, up2 = (b & 2) != 0, up4 = (b & 4) != 0;
+      long long v1[8];
 #pragma unroll
-      for (int d = 1; d <= 4; d <<= 1) {
-        const bool up = (b & d) != 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if ((i & d) == 0) {
-            // lanes with bit d clear trade their register i|d for the partner's register i.
-            // (the empty asm pins both values in registers: without it hipcc folds the select into a
-            // runtime register index and expands every access into a 16-way v_cndmask chain)
-            int xi = x[i], xj = x[i | d];
-            asm("" : "+v"(xi));
-            asm("" : "+v"(xj));
-            const int send = up ? xi : xj;
-            const int recv = xor_lane_dpp(send, d);
-            x[i] = up ? recv : xi;
-            x[i | d] = up ? xj : recv;
-          }
-        }
+      for (int tq = 0; tq < 8; ++tq) {
+        int xe = x[2 * tq], xo = x[2 * tq + 1];
+        asm("" : "+v"(xe));
+        asm("" : "+v"(xo));
+        const int keep = up1 ? xo : xe, send = up1 ? xe : xo;
+        const int recv = xor_lane_dpp(send, 1);
+        const int lo_t = up1 ? recv : keep, hi_t = up1 ? keep : recv;
+        v1[tq] = (long long)lo_t + ((long long)hi_t << 8);
       }
-      // now x[i] (i < 8) = digit i of the row of original register b, x[8+i] = digit i of register b+8
+      long long v2[4];
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq) {
+        long long ve = v1[2 * sq], vo = v1[2 * sq + 1];
+        asm("" : "+v"(ve));
+        asm("" : "+v"(vo));
+        const long long keep = up2 ? vo : ve, send = up2 ? ve : vo;
+        const long long recv = (long long)(((u64)(u32)xor_lane_dpp((int)((u64)send >> 32), 2) << 32) | (u32)xor_lane_dpp((int)(u32)send, 2));
+        const long long lo_t = up2 ? recv : keep, hi_t = up2 ? keep : recv;
+        v2[sq] = lo_t + (hi_t << 16);
+      }
 #pragma unroll
       for (int z = 0; z < 2; ++z) {
+        long long ve = v2[2 * z], vo = v2[2 * z + 1];
+        asm("" : "+v"(ve));
+        asm("" : "+v"(vo));
+        const long long keep = up4 ? vo : ve, send = up4 ? ve : vo;
+        const long long recv = (long long)(((u64)(u32)xor_lane_dpp((int)((u64)send >> 32), 4) << 32) | (u32)xor_lane_dpp((int)(u32)send, 4));
+        const long long lo4 = up4 ? recv : keep, hi4 = up4 ? keep : recv;      // each |.| < 2^52
         const u32 tt = b + 8 * z;
         const u32 row = (rt0 + r) * 32 + (tt & 3) + 8 * (tt >> 2) + 4 * h;
-        long long lo4 = 0, hi4 = 0;                                            // each < 2^27 * 2^24 * 4 < 2^53
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          lo4 += (long long)x[8 * z + i] << (8 * i);
-          hi4 += (long long)x[8 * z + 4 + i] << (8 * i);
-        }
-        const __int128 tot = (__int128)lo4 + ((__int128)hi4 << 32);
-        if (row < sec.nrows && v < nv) {
+        u64 res;
+        if constexpr (FASTQ) {
+          // (lo4 + hi4 * 2^32) mod q for q > 2^53: |lo4| < q already; hi4 * 2^32 through a quotient estimated
+          // in f64 (|hi4| < 2^52 is exact, the estimate is off by at most one) and two corrections
+          const u64 ah = (u64)(hi4 < 0 ? -hi4 : hi4), al = (u64)(lo4 < 0 ? -lo4 : lo4);
+          const u64 qhat = (u64)((double)ah * inv32);
+          long long rr = (long long)((ah << 32) - qhat * m.q);
+          if (rr < 0) rr += (long long)m.q;
+          if (rr >= (long long)m.q) rr -= (long long)m.q;
+          u64 rh = (u64)rr;
+          if (hi4 < 0 && rh) rh = m.q - rh;
+          const u64 rl = (lo4 < 0 && al) ? m.q - al : al;
+          res = addmod(rh, rl, m.q);
+        } else {
+          const __int128 tot = (__int128)lo4 + ((__int128)hi4 << 32);
           u64 lo = (u64)tot, hi = (u64)((unsigned __int128)tot >> 64);
           const bool neg = (long long)hi < 0;
           if (neg) { lo = ~lo + 1; hi = ~hi + (lo == 0); }
-          u64 res = reduce128(lo, hi, m);
+          res = reduce128(lo, hi, m);
           if (neg && res) res = m.q - res;
-          // intermediate [limb][slot][v][row]: the 16 lanes of one vector write 16 consecutive rows
-          sec.tmp[vb * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res;
         }
+        // intermediate [limb][slot][v][row]: the 16 lanes of one vector write 16 consecutive rows
+        if (row < sec.nrows && v < nv)
+          sec.tmp[vb * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res;
       }
     }
   }
@@ -2244,7 +2267,11 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   const size_t yd_b16 = yd_bytes(16, k, L, ell), sy_b16 = sy_bytes(16, L, ell) / sizeof(int);
   u32 dbg = 0;
   if (const char* e = getenv("PVW_GEMM_DEBUG")) dbg = (u32)atoi(e);
-#define PVW_GEMM_LAUNCH(G, N) PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16))
+#define PVW_GEMM_LAUNCH(G, N)                                                                                              \
+  do {                                                                                                                    \
+    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, true><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16)); } \
+    else { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, false><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16)); } \
+  } while (0)
   // fully unrolled chunk loops for the BASELINE geometries (k = 256: 8 chunks of 8 j-blocks, k = 512: 16), full vector groups
   static int unroll_ok = [] { const char* e = getenv("PVW_GEMM_UNROLL"); return e ? atoi(e) : 1; }();
   if (NVG == 4 && unroll_ok && !(dbg & 1) && k == 256) { PVW_GEMM_LAUNCH(4, 8); }
