@@ -372,6 +372,8 @@ def test_multi_dealer_encrypt_equals_separate_encrypts(D):
     (10, 6, 16, 3, 21),       # l = 16, two passes of 16 + 5 dealers
     (5, 12, 32, 2, 8),        # l = 32
     (200, 256, 8, 17, 8),     # config-3 geometry (k=256, 17 limbs) at a small party count
+    (100, 256, 8, 3, 40),     # k = 256: fully unrolled chunk loop, three batches (16 + 16 + 8) in one launch
+    (40, 512, 16, 2, 17),     # k = 512: the 16-chunk unrolled form, one full batch + one dealer
 ])
 def test_digit_gemm_multi_dealer_equals_separate_encrypts(n, k, l, L, D):
     # >= 8 dealers take the matrix-core path (gemm_digits_kernel): i8 MFMA over byte-folded operands
@@ -539,6 +541,29 @@ def test_config4_geometry_keygen_encrypt_decrypt():
         assert np.array_equal(noisy, orc.decrypt_noisy(sk[i], ct.c1[None], ct.c2[i][None]))
         got.append(vals[0])
     assert got == [int(x) for x in scalars]
+
+
+def test_batched_keygen_super_groups_against_c_oracle():
+    # pvw_keygen over more than one super-group of 128 parties (public_key.rs:111-147, crs.rs:138-171) at
+    # k = 256: sampling, NTTs, digit extraction, ONE gemm launch per super-group, re-tiling -- against the C
+    # restatement, with seeded and with explicit key errors
+    n, k, l, L = 150, 256, 8, 2
+    moduli = M.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    seed = bytes([0x5A]) * 32
+    crs = P.PvwCrs.new_deterministic(p, seed)
+    orc = O.Oracle(moduli, l)
+    a_hat = crs.matrix(P.REPR_NTT)
+    sk = O.sample_cbd(seed, M.DOM_SK, 0, n * k, l, 0.5).reshape(n, k, l)
+    ek = O.sample_uniform(seed, M.DOM_EKEY, 0, n * k, l, 100).reshape(n, k, l)
+    want = orc.keygen(a_hat, sk, ek)
+    gpk = P.GlobalPublicKey.new(crs)
+    parties = [P.Party.new(i, p, seed) for i in range(n)]
+    gpk.generate_all_party_keys(parties, seed)
+    assert np.array_equal(gpk.matrix(repr=P.REPR_NTT), want)
+    gpk2 = P.GlobalPublicKey.new(crs)
+    gpk2.generate_with_errors(0, sk, ek)
+    assert np.array_equal(gpk2.matrix(repr=P.REPR_NTT), want)
 
 
 def test_config2_full_size_against_c_oracle():
