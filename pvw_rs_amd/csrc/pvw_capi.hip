@@ -1220,19 +1220,25 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
   u64* vh = use_gemm ? w->vhat16 : w->rhat;
   for (size_t d0 = 0; d0 < D; d0 += group) {
     const u32 nv = (u32)((D - d0) < group ? (D - d0) : group);
-    // prologues, up to eight dealers per launch: r-hat_d -> vh[v], NTT(e1), NTT(e2) + m*g-hat -> output planes
-    for (u32 v0 = 0; v0 < nv; v0 += 8) {
-      const u32 cnt = (nv - v0) < 8 ? (nv - v0) : 8;
+    // prologue: the (r, e1, e2) families of dealer d0 replicated over the nv dealers of this pass (up to 64 keys
+    // per launch): r-hat_d -> vh[v], NTT(e1), NTT(e2) + m*g-hat -> output planes
+    for (u32 v0 = 0; v0 < nv; v0 += PVW_MAX_PROLOGUE_KEYS) {
+      const u32 cnt = (nv - v0) < PVW_MAX_PROLOGUE_KEYS ? (nv - v0) : PVW_MAX_PROLOGUE_KEYS;
+      const size_t d = d0 + v0;
       PrologueBatch pb{};
-      for (u32 x = 0; x < cnt; ++x) {
-        const size_t d = d0 + v0 + x;
-        pvw_randomness_t rnd{};
-        rnd.mode = PVW_RND_SEED;
-        memcpy(rnd.seed, seeds + d * 32, 32);
-        PVW_TRY(fill_encrypt_jobs(c, pb, x, 0, &rnd, d_scalars + d * c->n, vh + (size_t)(v0 + x) * k * P,
-                                  d_c1 + d * rA * P, d_c2 + d * rB * P));
-      }
-      pb.njobs = 3 * cnt;
+      pvw_randomness_t rnd{};
+      rnd.mode = PVW_RND_SEED;
+      memcpy(rnd.seed, seeds + d * 32, 32);
+      PVW_TRY(fill_encrypt_jobs(c, pb, 0, 0, &rnd, d_scalars + d * c->n, vh + (size_t)v0 * k * P,
+                                d_c1 + d * rA * P, d_c2 + d * rB * P));
+      for (u32 x = 0; x < cnt; ++x) pb.key[x] = make_key(seeds + (d + x) * 32);
+      pb.job[0].rep_key = pb.job[1].rep_key = pb.job[2].rep_key = 1;
+      pb.job[0].rep_out = (size_t)k * P;                       // r-hat vectors
+      pb.job[1].rep_out = (size_t)rA * P;                      // c1 planes
+      pb.job[2].rep_out = (size_t)rB * P;                      // c2 planes
+      pb.job[2].rep_scalars = c->n;
+      pb.njobs = 3;
+      pb.reps = cnt;
       ProfScope ps(c, "prologue", s);
       PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
     }
@@ -1652,16 +1658,19 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
         u64* vh = w->rhat;
         PrologueBatch pb{};
         if (seed) pb.key[0] = make_key(seed);
-        for (u32 v = 0; v < nv; ++v) {
-          PrologueJob& js = pb.job[2 * v];
-          PrologueJob& je = pb.job[2 * v + 1];
-          js.sj.count = k; js.explicit_coeffs = d_small + (size_t)(in_chunk + v) * k * l;    // secret_key.rs:98-112
-          js.out = vh + (size_t)v * k * P; js.stride_poly = l; js.stride_limb = (size_t)k * l;
-          je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = (p0 + v) * k; je.sj.count = k; je.sj.bound = c->b1;  // public_key.rs:128-132
-          if (ek) je.explicit_coeffs = d_small + (size_t)(chunk + in_chunk + v) * k * l;
-          je.out = d_row + (size_t)v * k * P; je.stride_poly = P; je.stride_limb = l;
+        {
+          PrologueJob& js = pb.job[0];
+          PrologueJob& je = pb.job[1];
+          js.sj.count = k; js.explicit_coeffs = d_small + (size_t)in_chunk * k * l;              // secret_key.rs:98-112
+          js.out = vh; js.stride_poly = l; js.stride_limb = (size_t)k * l;
+          js.rep_coeffs = (size_t)k * l; js.rep_out = (size_t)k * P;
+          je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = p0 * k; je.sj.count = k; je.sj.bound = c->b1;  // public_key.rs:128-132
+          je.rep_index0 = k;
+          if (ek) { je.explicit_coeffs = d_small + (size_t)(chunk + in_chunk) * k * l; je.rep_coeffs = (size_t)k * l; }
+          je.out = d_row; je.stride_poly = P; je.stride_limb = l; je.rep_out = (size_t)k * P;
         }
-        pb.njobs = 2 * nv;
+        pb.njobs = 2;
+        pb.reps = nv;
         ok2 = launch_prologue(pb, c->dt, L, l, s) == hipSuccess;
         MacSection sa{d_tt, d_row, d_row, k, 0}, sb{nullptr, nullptr, nullptr, 0, 0};
         MultiVec mv{vh, (size_t)k * P, (size_t)k * P, 0, nv};

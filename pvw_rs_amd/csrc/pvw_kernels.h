@@ -75,17 +75,23 @@ struct PrologueJob {
   const u64* scalars;
   u64* out;
   size_t stride_poly, stride_limb;
-  u32 key_idx;   // which key of the batch seeds this family
+  u32 key_idx;   // which key of the batch seeds this family (replica r uses key_idx + r * rep_key)
+  // replication (PrologueBatch::reps > 1): what replica r adds to the fields above
+  u32 rep_key;        // 0: every replica shares the key, 1: one key per replica
+  u32 rep_index0;     // stream index offset per replica
+  size_t rep_out, rep_scalars, rep_coeffs;   // element offsets per replica
 };
-#define PVW_MAX_PROLOGUE_JOBS 32
-#define PVW_MAX_PROLOGUE_KEYS 16
-// up to 10 encrypts' (r, e1, e2) or 16 key generations' (s, e) worth of polynomial families in one
-// launch; the whole batch travels in the kernel-argument segment (< 4 KiB)
+#define PVW_MAX_PROLOGUE_JOBS 8
+#define PVW_MAX_PROLOGUE_KEYS 64
+// The polynomial families of ONE encrypt (r, e1, e2) or ONE key generation (s, e), replicated `reps` times
+// with regular strides (up to 64 dealers / parties per launch); the whole batch travels in the
+// kernel-argument segment (< 4 KiB)
 struct PrologueBatch {   // sizeof must stay below the 4 KiB kernel-argument limit
   PrologueJob job[PVW_MAX_PROLOGUE_JOBS];
   ChaChaKey key[PVW_MAX_PROLOGUE_KEYS];
   u32 njobs;
-  u32 total;   // filled in by the launcher
+  u32 reps;    // 0 is read as 1
+  u32 total;   // filled in by the launcher (polynomials per replica)
   u32 debug;   // filled in by the launcher (timing experiments)
 };
 hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s);

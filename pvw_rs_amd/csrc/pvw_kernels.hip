@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64) void sample_kernel(i64* __restrict__ out, ChaCh
 
 // ------------------------------------------------------------------------------------
 // prologue: everything encrypt needs before the streamed MAC, in ONE launch
-// (encryption.rs:135-154 r, :161-167 e1, :195-196 encode + e2): each block takes PB
+// (encryption.rs:135-154 r, :161-167 e1, :195-196 encode + e2): each block takes PB <= 64
 // polynomials, samples (or copies) their small coefficients into LDS with one thread per
 // polynomial, then one thread per (polynomial, limb) reduces, transforms and stores.
 // ------------------------------------------------------------------------------------
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
   u64* tab = psm + (size_t)PB * ELL;                  // [4][L][ELL] tw | twp | ghat | ghatp (if staged)
   const u32 gp0 = blockIdx.x * PB;
   const u32 tid = threadIdx.x;
+  const u32 rep = blockIdx.y;                         // replica (dealer / party) of the template jobs
   // locate (job, local polynomial) of global polynomial gp: jobs are laid end to end
   auto locate = [&](u32 gp, u32& ji, u32& local) {
     ji = 0;
@@ -618,17 +619,18 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
     for (u32 x = 0; x + 1 < PVW_MAX_PROLOGUE_JOBS; ++x)
       if (ji == x && x + 1 < b.njobs && local >= b.job[x].sj.count) { local -= b.job[x].sj.count; ji = x + 1; }
   };
-  if (tid < PB && gp0 + tid < b.total && !(b.debug & 1)) {
+  if (tid < PB && tid < 64 && gp0 + tid < b.total && !(b.debug & 1)) {
     u32 ji, local;
     locate(gp0 + tid, ji, local);
     const PrologueJob& job = b.job[ji];
     i64* o = sc + tid * ELL;
     if (job.explicit_coeffs) {
+      const i64* ec = job.explicit_coeffs + (size_t)rep * job.rep_coeffs;
 #pragma unroll
-      for (int s = 0; s < ELL; ++s) o[s] = job.explicit_coeffs[(size_t)local * ELL + s];
+      for (int s = 0; s < ELL; ++s) o[s] = ec[(size_t)local * ELL + s];
     } else {
       ChaChaRng g;
-      g.init(b.key[job.key_idx], job.sj.domain, job.sj.index0 + local);
+      g.init(b.key[job.key_idx + rep * job.rep_key], job.sj.domain, job.sj.index0 + rep * job.rep_index0 + local);
       auto emit = [o](u32 s, i64 v) { o[s] = v; };
       if (job.sj.kind == SAMPLE_CBD) sample_cbd_poly(g, ELL, job.sj.cbd_half != 0, job.sj.cbd_v, emit);
       else sample_uniform_poly(g, ELL, job.sj.bound, emit);
@@ -644,29 +646,33 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
     }
   }
   __syncthreads();
-  const u32 p = tid / L, limb = tid % L;
-  if (p >= PB || gp0 + p >= b.total || (b.debug & 2)) return;
-  u32 ji, local;
-  locate(gp0 + p, ji, local);
-  const PrologueJob& job = b.job[ji];
-  const Mod m = t.mods[limb];
+  if (b.debug & 2) return;
   const u32 n = L * ELL;
-  const u64* tw = stage_tables ? tab + (size_t)limb * ELL : t.tw + (size_t)limb * ELL;
-  const u64* twp = stage_tables ? tab + n + (size_t)limb * ELL : t.twp + (size_t)limb * ELL;
-  u64 a[ELL];
+  // one thread per (polynomial, limb); a block of PB <= 64 polynomials takes ceil(PB * L / 256) trips
+  for (u32 idx = tid; idx < PB * L; idx += 256) {
+    const u32 p = idx / L, limb = idx % L;
+    if (gp0 + p >= b.total) break;
+    u32 ji, local;
+    locate(gp0 + p, ji, local);
+    const PrologueJob& job = b.job[ji];
+    const Mod m = t.mods[limb];
+    const u64* tw = stage_tables ? tab + (size_t)limb * ELL : t.tw + (size_t)limb * ELL;
+    const u64* twp = stage_tables ? tab + n + (size_t)limb * ELL : t.twp + (size_t)limb * ELL;
+    u64 a[ELL];
 #pragma unroll
-  for (int s = 0; s < ELL; ++s) a[s] = signed_residue(sc[p * ELL + s], m);
-  ntt_forward<ELL>(a, tw, twp, m);
-  if (job.scalars) {
-    const u64 mr = signed_residue((i64)job.scalars[local], m);   // `as i64` wrap, encryption.rs:195
-    const u64* g = stage_tables ? tab + 2 * n + (size_t)limb * ELL : t.ghat + (size_t)limb * ELL;
-    const u64* gp = stage_tables ? tab + 3 * n + (size_t)limb * ELL : t.ghatp + (size_t)limb * ELL;
+    for (int s = 0; s < ELL; ++s) a[s] = signed_residue(sc[p * ELL + s], m);
+    ntt_forward<ELL>(a, tw, twp, m);
+    if (job.scalars) {
+      const u64 mr = signed_residue((i64)job.scalars[(size_t)rep * job.rep_scalars + local], m);   // `as i64` wrap, encryption.rs:195
+      const u64* g = stage_tables ? tab + 2 * n + (size_t)limb * ELL : t.ghat + (size_t)limb * ELL;
+      const u64* gp = stage_tables ? tab + 3 * n + (size_t)limb * ELL : t.ghatp + (size_t)limb * ELL;
 #pragma unroll
-    for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod_shoup(mr, g[s], gp[s], m.q), m.q);
+      for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod_shoup(mr, g[s], gp[s], m.q), m.q);
+    }
+    u64* o = job.out + (size_t)rep * job.rep_out + (size_t)local * job.stride_poly + (size_t)limb * job.stride_limb;
+#pragma unroll
+    for (int s = 0; s < ELL; s += 2) *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
   }
-  u64* o = job.out + (size_t)local * job.stride_poly + (size_t)limb * job.stride_limb;
-#pragma unroll
-  for (int s = 0; s < ELL; s += 2) *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
 }
 
 // truncated discrete Gaussian (src/sampling/normal.rs:136-190): one thread per sample.
@@ -2098,16 +2104,24 @@ hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L
   static u32 dbg = [] { const char* e = getenv("PVW_PROLOGUE_DEBUG"); return e ? (u32)atoi(e) : 0u; }();
   b.debug = dbg;   // timing experiments only: 1 = skip sampling, 2 = skip transform
   if (b.njobs > PVW_MAX_PROLOGUE_JOBS) return hipErrorInvalidValue;
-  for (u32 i = 0; i < b.njobs; ++i) b.total += b.job[i].sj.count;
+  if (b.reps == 0) b.reps = 1;
+  if (b.reps > 65535) return hipErrorInvalidValue;
+  for (u32 i = 0; i < b.njobs; ++i) {
+    b.total += b.job[i].sj.count;
+    if (b.job[i].key_idx + (b.reps - 1) * b.job[i].rep_key >= PVW_MAX_PROLOGUE_KEYS) return hipErrorInvalidValue;
+  }
   if (b.total == 0) return hipSuccess;
   if (L > 256) return hipErrorInvalidValue;
+  // polynomials per block: 256/L (one trip of the transform loop, lowest latency) for one encrypt's worth of
+  // work; a whole wave of samplers (64) when the launch is large enough to fill the chip anyway
   u32 PB = 256 / L;
   if (PB > 64) PB = 64;
+  if ((size_t)b.total * b.reps >= 65536) PB = 64;
   const u32 blocks = (b.total + PB - 1) / PB;
   const size_t sc_bytes = (size_t)PB * ell * 8, tab_bytes = (size_t)4 * L * ell * 8;
   const u32 stage = (sc_bytes + tab_bytes <= 64 * 1024) ? 1u : 0u;
   const size_t lds = sc_bytes + (stage ? tab_bytes : 0);
-  PVW_DISPATCH_ELL(ell, prologue_kernel<E><<<dim3(blocks), dim3(256), lds, s>>>(b, L, PB, stage, t));
+  PVW_DISPATCH_ELL(ell, prologue_kernel<E><<<dim3(blocks, b.reps), dim3(256), lds, s>>>(b, L, PB, stage, t));
   return hipGetLastError();
 }
 
