@@ -10,7 +10,7 @@ import pytest
 import pvw_model as M
 import pvw_oracle as O
 import pvw_rs_amd as P
-from _util import EXAMPLE_MODULI, SEED, TEST_MODULI, make_system, primes_1mod
+from _util import EXAMPLE_MODULI, SEED, TEST_MODULI, make_system, primes_1mod, rns_to_ring
 
 pytestmark = pytest.mark.gpu
 
@@ -541,6 +541,66 @@ def test_config4_geometry_keygen_encrypt_decrypt():
         assert np.array_equal(noisy, orc.decrypt_noisy(sk[i], ct.c1[None], ct.c2[i][None]))
         got.append(vals[0])
     assert got == [int(x) for x in scalars]
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_geometries_full_pipeline_against_c_oracle(case):
+    # seeded random (n, k, l, L, D, variance, bounds): key generation, single- and multi-dealer encrypt, batched
+    # decrypt and decode, each against the C restatement / the big-integer model -- the reference's own tests
+    # walk a handful of fixed geometries (tests/crypto.rs, tests/keys.rs); this widens them
+    rng = np.random.default_rng(1000 + case)
+    for _ in range(50):                      # redraw until the reference's correctness gate (parameters.rs:510-551) passes
+        l = int(rng.choice([8, 8, 16, 32]))
+        L = int(rng.integers(1, 7))
+        k = int(rng.integers(1, 70))
+        n = int(rng.integers(1, 60))
+        D = int(rng.integers(1, 40))
+        variance = float(rng.choice([0.5, 1.0, 2.0, 3.0]))
+        b1, b2 = int(rng.integers(1, 500)), int(rng.integers(1, 5000))
+        moduli = M.bench_moduli(L)
+        p = build_params(n, k, l, moduli, variance, (b1, b2))
+        if p.verify_correctness_condition():
+            break
+    else:
+        pytest.fail("no geometry passed the correctness gate")
+    seed = bytes([17 + case]) * 32
+    orc = O.Oracle(moduli, l)
+    crs = P.PvwCrs.new_deterministic(p, seed)
+    a_hat = crs.matrix(P.REPR_NTT)
+    gpk = P.GlobalPublicKey.new(crs)
+    parties = [P.Party.new(i, p, seed) for i in range(n)]
+    gpk.generate_all_party_keys(parties, seed)
+    sk = O.sample_cbd(seed, M.DOM_SK, 0, n * k, l, variance).reshape(n, k, l)
+    ek = O.sample_uniform(seed, M.DOM_EKEY, 0, n * k, l, b1).reshape(n, k, l)
+    b_hat = gpk.matrix(repr=P.REPR_NTT)
+    assert np.array_equal(b_hat, orc.keygen(a_hat, sk, ek)), "keygen"
+    g_hat = p.gadget_polynomial(P.REPR_NTT)
+    rows = [[int(x) for x in rng.integers(0, 1 << 32, size=n, dtype=np.uint64)] for _ in range(D)]
+    seeds = [P.api._dealer_seed(seed, d) for d in range(D)]
+    many = P.encrypt_many(rows, gpk, seeds)
+    for d in (0, D // 2, D - 1):
+        r = O.sample_cbd(seeds[d], M.DOM_R, 0, k, l, variance)
+        e1 = O.sample_uniform(seeds[d], M.DOM_E1, 0, k, l, b1)
+        e2 = O.sample_uniform(seeds[d], M.DOM_E2, 0, n, l, b2)
+        c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, np.array(rows[d], dtype=np.uint64), r, e1, e2)
+        assert np.array_equal(many[d].c1, c1o) and np.array_equal(many[d].c2, c2o), f"multi-dealer encrypt {d}"
+        one = P.encrypt(rows[d], gpk, seeds[d])
+        assert np.array_equal(one.c1, c1o) and np.array_equal(one.c2, c2o), f"encrypt {d}"
+    # party i decrypts its share from every dealer
+    mparams = M.Params(n, k, l, moduli)
+    for i in (0, n - 1):
+        vals, noisy = P.api._decrypt_batch(p, many, parties[i].secret_key, i, return_noisy=True)
+        c1s = np.stack([ct.c1 for ct in many])
+        c2col = np.stack([ct.c2[i] for ct in many])
+        want_noisy = orc.decrypt_noisy(sk[i], c1s, c2col)
+        assert np.array_equal(noisy, want_noisy), f"decrypt party {i}"
+        lifted = [rns_to_ring(want_noisy[d], moduli) for d in range(D)]
+        assert vals == [M.decode_scalar_pvw(z, mparams) for z in lifted], f"decode party {i}"
+        # Recovery of the scalars is a property of the scheme, not of this implementation (device == model above).
+        # The gate does not look at the message size, so only geometries whose Delta exceeds the 32-bit scalars
+        # are held to the reference's own >= 95 % (tests/crypto.rs:295-304).
+        if mparams.delta.bit_length() > 34:
+            assert sum(v == rows[d][i] for d, v in enumerate(vals)) >= 0.95 * D - 1
 
 
 def test_batched_keygen_super_groups_against_c_oracle():
