@@ -1920,28 +1920,62 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 }
 
 // gemm_finish: intermediate [limb][slot][v][row] -> API layout out[v][row][limb][slot] (+ addend),
-// 256-byte runs in, 8*l-byte runs out, through an LDS tile of 32 rows x l slots.
+// 256-byte runs in, 8*l-byte runs out, through LDS tiles of 32 rows x l slots; one block takes VPB = 4
+// vectors so that four tiles' worth of loads are in flight per thread.
+#define PVW_FINISH_VPB (ELL >= 64 ? 2 : 4)
 template <int ELL>
 __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const Mod* __restrict__ mods, u32 L,
                                                            u32 nv, u32 nv_pad, u32 rows_pad, size_t ostride) {
-  __shared__ u64 tile[ELL][33];
-  const u32 rb = blockIdx.x, v = blockIdx.y, limb = blockIdx.z;
+  constexpr int VPB = PVW_FINISH_VPB, PT = 32 * ELL / 256 ? 32 * ELL / 256 : 1;   // elements per thread per tile
+  static_assert(sizeof(u64) * VPB * ELL * 33 <= 48 * 1024 || ELL > 32, "finish tiles");
+  __shared__ u64 tile[VPB][ELL][33];
+  const u32 rb = blockIdx.x, v0 = blockIdx.y * VPB, limb = blockIdx.z;
   const u32 row0 = rb * 32;
-  for (u32 e = threadIdx.x; e < 32 * ELL; e += 256) {
-    const u32 row = e & 31, slot = e >> 5;
-    tile[slot][row] = sec.tmp[(v >> 4) * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + (nv_pad == 16 ? (v & 15) : v)) * rows_pad + row0 + row];
-  }
-  __syncthreads();
-  const u64 q = mods[limb].q;
-  for (u32 e = threadIdx.x; e < 32 * ELL; e += 256) {
-    const u32 slot = e % ELL, row = e / ELL;
-    if (row0 + row < sec.nrows) {
-      const size_t o = (size_t)v * ostride + ((size_t)(row0 + row) * L + limb) * ELL + slot;
-      u64 res = tile[slot][row];
-      if (sec.addend) res = addmod(res, sec.addend[o], q);
-      sec.out[o] = res;
+  u64 in[VPB][PT];
+#pragma unroll
+  for (int vi = 0; vi < VPB; ++vi) {
+    const u32 v = (v0 + vi) < nv ? (v0 + vi) : (nv - 1);
+    const u64* tp = sec.tmp + (v >> 4) * sec.tmp_bstride + (((size_t)limb * ELL) * nv_pad + (nv_pad == 16 ? (v & 15) : v)) * rows_pad + row0;
+#pragma unroll
+    for (int x = 0; x < PT; ++x) {
+      const u32 e = threadIdx.x + 256 * x;
+      const u32 row = e & 31, slot = (e >> 5) % ELL;
+      in[vi][x] = tp[(size_t)slot * nv_pad * rows_pad + row];
     }
   }
+#pragma unroll
+  for (int vi = 0; vi < VPB; ++vi)
+#pragma unroll
+    for (int x = 0; x < PT; ++x) {
+      const u32 e = threadIdx.x + 256 * x;
+      if (e < 32 * ELL) tile[vi][(e >> 5) % ELL][e & 31] = in[vi][x];
+    }
+  __syncthreads();
+  const u64 q = mods[limb].q;
+  u64 add[VPB][PT];
+  const bool has_add = sec.addend != nullptr;
+#pragma unroll
+  for (int vi = 0; vi < VPB; ++vi)
+#pragma unroll
+    for (int x = 0; x < PT; ++x) {
+      const u32 e = threadIdx.x + 256 * x;
+      const u32 slot = e % ELL, row = (e / ELL) & 31;
+      const u32 v = (v0 + vi) < nv ? (v0 + vi) : (nv - 1);
+      const u32 rr = (row0 + row) < sec.nrows ? (row0 + row) : 0;
+      const size_t o = (size_t)v * ostride + ((size_t)rr * L + limb) * ELL + slot;
+      add[vi][x] = has_add ? sec.addend[o] : 0;
+    }
+#pragma unroll
+  for (int vi = 0; vi < VPB; ++vi)
+#pragma unroll
+    for (int x = 0; x < PT; ++x) {
+      const u32 e = threadIdx.x + 256 * x;
+      const u32 slot = e % ELL, row = e / ELL;
+      if (e < 32 * ELL && row0 + row < sec.nrows && v0 + vi < nv) {
+        const size_t o = (size_t)(v0 + vi) * ostride + ((size_t)(row0 + row) * L + limb) * ELL + slot;
+        sec.out[o] = addmod(tile[vi][slot][row], add[vi][x], q);
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2299,11 +2333,11 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   }
 #undef PVW_GEMM_LAUNCH
   if (sa.nrows) {
-    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sa.nrows + 31) / 32, nv, L), dim3(256), 0, s>>>(
+    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sa.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
                               sa, t.mods, L, nv, nv_pad, sa.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_a));
   }
   if (sb.nrows) {
-    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sb.nrows + 31) / 32, nv, L), dim3(256), 0, s>>>(
+    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sb.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
                               sb, t.mods, L, nv, nv_pad, sb.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_b));
   }
   return hipGetLastError();
