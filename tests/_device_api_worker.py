@@ -100,7 +100,59 @@ def main():
     vals, noisy = P.api._decrypt_batch(p, cts, P.SecretKey.from_coefficients(p, sk), 3, return_noisy=True)
     assert np.array_equal(d_noisy.cpu().numpy().view(np.uint64), noisy)
     assert [int(v) for v in d_vals.cpu().numpy().view(np.uint64)] == vals
+    config5_full_size(lib, stream, dev)
     print("DEVICE_API_OK")
+
+
+def config5_full_size(lib, stream, dev):
+    """BASELINE.json configs[4] at full size on ONE GPU: D = 8192 dealer ciphertexts, k = 512, l = 16, 34 limbs:
+    18.25 GB of stacked c1, synthetic residues generated on the device.  Sampled dealers' noisy polynomials
+    against the C restatement, every decoded value against the model's decode of the device's noisy polynomial
+    (decode is checked exhaustively elsewhere), and linearity: decrypt(c2 + delta) - decrypt(c2) = -delta."""
+    import pvw_model as M
+    import pvw_oracle as O
+    D, k, l, L = 8192, 512, 16, 34
+    moduli = M.bench_moduli(L)
+    p = (P.PvwParametersBuilder().set_parties(4).set_dimension(k).set_l(l).set_moduli(moduli)
+         .set_secret_variance(0.5).set_error_bounds(100, 200).build())
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    qmin = min(moduli)
+    d_c1s = torch.randint(0, qmin, (D, k, L, l), dtype=torch.int64, device=dev, generator=g)     # residues < every q_i
+    d_c2col = torch.randint(0, qmin, (D, L, l), dtype=torch.int64, device=dev, generator=g)
+    sk = p.sample_vec_cbd(bytes([9]) * 32, P.DOM_SK, 0, k)
+    d_sk = torch.from_numpy(sk).to(dev)
+    d_noisy = torch.zeros((D, L, l), dtype=torch.int64, device=dev)
+    d_vals = torch.zeros(D, dtype=torch.int64, device=dev)
+    P.api._check(lib.pvw_decrypt_noisy_device(p._h, ptr(d_sk), ptr(d_c1s), ptr(d_c2col), D, P.REPR_NTT, ptr(d_noisy), stream))
+    P.api._check(lib.pvw_decode_device(p._h, ptr(d_noisy), D, ptr(d_vals), stream))
+    torch.cuda.synchronize()
+    orc = O.Oracle(moduli, l)
+    pick = [0, 1, 4095, 4096, 8190, 8191]
+    c1_h = np.stack([d_c1s[d].cpu().numpy().view(np.uint64) for d in pick])
+    c2_h = np.stack([d_c2col[d].cpu().numpy().view(np.uint64) for d in pick])
+    want = orc.decrypt_noisy(sk, c1_h, c2_h)
+    got = np.stack([d_noisy[d].cpu().numpy().view(np.uint64) for d in pick])
+    assert np.array_equal(got, want), "config-5 full size: noisy polynomials"
+    mp = M.Params(4, k, l, moduli)
+    vals = d_vals.cpu().numpy().view(np.uint64)
+    for d, z in zip(pick, got):
+        lifted = M.from_rns([[int(v) for v in row] for row in z], list(moduli))
+        assert int(vals[d]) == M.decode_scalar_pvw(lifted, mp), "config-5 full size: decode"
+    # linearity over ALL dealers: delta added to every NTT slot of c2 is the constant polynomial delta, so the
+    # noisy polynomial (power basis) loses delta in coefficient 0 and nothing elsewhere, limb-wise
+    delta = 12345
+    d_c2b = d_c2col + delta
+    for i, q in enumerate(moduli):
+        d_c2b[:, i] %= q
+    d_noisy2 = torch.zeros_like(d_noisy)
+    P.api._check(lib.pvw_decrypt_noisy_device(p._h, ptr(d_sk), ptr(d_c1s), ptr(d_c2b), D, P.REPR_NTT, ptr(d_noisy2), stream))
+    d_noisy1 = torch.zeros_like(d_noisy)
+    P.api._check(lib.pvw_decrypt_noisy_device(p._h, ptr(d_sk), ptr(d_c1s), ptr(d_c2col), D, P.REPR_NTT, ptr(d_noisy1), stream))
+    torch.cuda.synchronize()
+    for i, q in enumerate(moduli):
+        diff = (d_noisy1[:, i] - d_noisy2[:, i]) % q
+        assert bool((diff[:, 0] == delta).all()) and bool((diff[:, 1:] == 0).all()), "config-5 full size: linearity"
 
 
 if __name__ == "__main__":

@@ -652,3 +652,31 @@ def test_config2_full_size_against_c_oracle():
         want = (5 * g[i].astype(object)) % q
         assert (diff == want[None, :]).all()
     assert np.array_equal(ct1.c1, ct2.c1)
+
+
+def test_config4_full_size_sampled_rows_against_c_oracle():
+    # BASELINE.json configs[3] on ONE GPU at full size: n = 16384, k = 512, l = 16, 34 limbs (2074-bit Q); B-hat
+    # is 36.5 GB.  All of c1 and three windows of c2 rows (first, middle, last) against the C restatement on the
+    # same synthetic A-hat / B-hat: a size the 32-bit index arithmetic of a kernel would not survive by accident.
+    n, k, l, L = 16384, 512, 16, 34
+    moduli = M.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    sa, sb = bytes([0xA]) * 32, bytes([0xB]) * 32
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, sa))
+    gpk.fill_uniform(sb)
+    scalars = np.array([(i * 1000 + 1) % (1 << 32) for i in range(n)], dtype=np.uint64)
+    ct = P.encrypt(scalars, gpk, SEED)
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(sa, M.DOM_CRS, 0, k * k).reshape(k, k, L, l)
+    r = O.sample_cbd(SEED, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
+    g_hat = p.gadget_polynomial(P.REPR_NTT)
+    for lo in (0, n // 2 - 3, n - 8):
+        rows = 8
+        b_sub = orc.fill_uniform(sb, M.DOM_PK, lo * k, rows * k).reshape(rows, k, L, l)
+        assert np.array_equal(gpk.matrix(lo, lo + rows, P.REPR_NTT), b_sub)
+        e2 = O.sample_uniform(SEED, M.DOM_E2, lo, rows, l, 200)
+        c1o, c2o = orc.encrypt(a_hat, b_sub, g_hat, scalars[lo:lo + rows], r, e1, e2)
+        assert np.array_equal(ct.c2[lo:lo + rows], c2o), f"c2 rows {lo}.."
+        if lo == 0:
+            assert np.array_equal(ct.c1, c1o), "c1"
