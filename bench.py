@@ -29,11 +29,13 @@ CONFIGS = {
     "c2": (1024, 256, 8, 17, "BASELINE configs[1]: n=1024, k=256, l=8, 1037-bit q"),
     "c3": (4096, 256, 8, 17, "BASELINE configs[2] / north-star target: n=4096, k=256, l=8, 1037-bit q (17 limbs)"),
     "c3x4": (16384, 256, 8, 17, "sizing experiment: config 3 geometry with n=16384 parties on one GPU"),
+    "c4full": (16384, 512, 16, 34, "BASELINE configs[3] in full on ONE GPU: n=16384, k=512, l=16, 2074-bit q (B-hat 36.5 GB)"),
     "c4shard": (2048, 512, 16, 34, "BASELINE configs[3] per-GPU shard: n=16384/8, k=512, l=16, 2074-bit q"),
 }
 DECRYPT_CONFIGS = {
     # name: (dealers per GPU, k, l, limbs, description)
     "c5shard": (1024, 512, 16, 34, "BASELINE configs[4] per-GPU shard: D=8192/8 dealer ciphertexts, k=512, l=16, 2074-bit q"),
+    "c5full": (8192, 512, 16, 34, "BASELINE configs[4] in full on ONE GPU: D=8192 dealer ciphertexts, k=512, l=16, 2074-bit q (18.3 GB)"),
     "d3": (2048, 256, 8, 17, "decrypt of D=2048 dealer ciphertexts at the config-3 geometry: k=256, l=8, 1037-bit q"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
