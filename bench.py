@@ -352,11 +352,10 @@ def bench_decrypt(args, world, rank, local_rank, dev):
     vals_dev = torch.zeros(D, dtype=torch.int64, device=dev)
 
     def step():
-        rc = lib.pvw_decrypt_noisy_device(h, C.c_void_p(sk.data_ptr()), C.c_void_p(c1s.data_ptr()),
+        # inner products, INTT and gadget decode on the device: only D x u64 would leave the GPU
+        rc = lib.pvw_decrypt_batch_device(h, C.c_void_p(sk.data_ptr()), C.c_void_p(c1s.data_ptr()),
                                           C.c_void_p(c2col.data_ptr()), D, P.REPR_NTT,
-                                          C.c_void_p(noisy.data_ptr()), stream)
-        if rc == 0:   # gadget decode on the device: only D x u64 would leave the GPU
-            rc = lib.pvw_decode_device(h, C.c_void_p(noisy.data_ptr()), D, C.c_void_p(vals_dev.data_ptr()), stream)
+                                          C.c_void_p(noisy.data_ptr()), C.c_void_p(vals_dev.data_ptr()), stream)
         if rc != 0:
             raise RuntimeError(_ffi.last_error())
 

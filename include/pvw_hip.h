@@ -220,6 +220,12 @@ PVW_API int32_t pvw_decrypt_batch(pvw_ctx* ctx, const int64_t* sk, const uint64_
 PVW_API int32_t pvw_decrypt_noisy_device(pvw_ctx* ctx, const int64_t* d_sk, const uint64_t* d_c1s,
                                  const uint64_t* d_c2col, size_t num_dealers, uint32_t in_repr,
                                  uint64_t* d_noisy, void* stream);
+/* decrypt_party_shares (decryption.rs:281-325) with device pointers end to end: d_noisy [D][L][l] is scratch /
+ * optional output (power basis), d_out [D] the decoded values.  Asynchronous on `stream`; internally the decode
+ * of one chunk of dealers overlaps the inner products of the next. */
+PVW_API int32_t pvw_decrypt_batch_device(pvw_ctx* ctx, const int64_t* d_sk, const uint64_t* d_c1s,
+                                 const uint64_t* d_c2col, size_t num_dealers, uint32_t in_repr,
+                                 uint64_t* d_noisy, uint64_t* d_out, void* stream);
 /* decode_scalar_pvw_rns alone, on the device: noisy [D][L][l] power basis (host) -> out_u64 [D] */
 PVW_API int32_t pvw_decode(pvw_ctx* ctx, const uint64_t* noisy, size_t count, uint64_t* out_u64);
 /* the same with host big integers on the host cores (no GPU needed): an independent

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "pvw_encrypt_multi_device": [_P, _P, C.c_size_t, C.c_size_t, _P, _P, _P, C.c_uint32, _P],
     "pvw_decrypt_batch": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P],
     "pvw_decrypt_noisy_device": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P],
+    "pvw_decrypt_batch_device": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P, _P],
     "pvw_decode": [_P, _P, C.c_size_t, _P],
     "pvw_decode_host": [_P, _P, C.c_size_t, _P],
     "pvw_decode_device": [_P, _P, C.c_size_t, _P, _P],

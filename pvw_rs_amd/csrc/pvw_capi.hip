@@ -125,6 +125,9 @@ struct Workspace {
   u64* gtmpA = nullptr;      // GEMM intermediates [limb][slot][v][row]
   u64* gtmpB = nullptr;
   u64* gtmpK = nullptr;      // ... for key generation (k rows)
+  // helper stream + events for pvw_decrypt_batch_device (decode of chunk i under the MAC of chunk i+1)
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> events;
 };
 
 struct pvw_ctx {
@@ -408,6 +411,8 @@ static void ws_free(Workspace* w) {
   hipFree(w->gtmpA);
   hipFree(w->gtmpB);
   hipFree(w->gtmpK);
+  for (hipEvent_t e : w->events) hipEventDestroy(e);
+  if (w->aux) hipStreamDestroy(w->aux);
   if (w->own_stream && w->stream) hipStreamDestroy(w->stream);
   delete w;
 }
@@ -1504,6 +1509,71 @@ int32_t pvw_decrypt_noisy_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
   Workspace* w;
   PVW_TRY(ws_for_stream(c, s, &w));
   return decrypt_enqueue(c, w, d_sk, const_cast<u64*>(d_c1s), const_cast<u64*>(d_c2col), D, in_repr, d_noisy, s, false);
+}
+
+// decrypt_party_shares with device pointers end to end: <sk, c1> - c2, INTT and gadget decode for D dealer
+// ciphertexts; only D x u64 are produced.  Large batches are cut into chunks of about 2 GiB and the
+// decode of chunk i (integer-ALU work, a few waves per CU) runs on a helper stream under the HBM-bound MAC of
+// chunk i+1; the caller's stream waits for the last decode before the call's work counts as complete.
+int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t* d_c1s, const uint64_t* d_c2col,
+                                 size_t D, uint32_t in_repr, uint64_t* d_noisy, uint64_t* d_out, void* stream) {
+  if (!c || !d_sk || ((!d_c1s || !d_c2col || !d_noisy || !d_out) && D)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(check_repr(in_repr));
+  if (in_repr != PVW_REPR_NTT) return fail(PVW_ERR_INVALID_FORMAT, "device decrypt takes NTT-domain ciphertexts");
+  if (D == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "No ciphertexts provided");          // decryption.rs:286-290
+  PVW_TRY(ensure_device(c));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  Workspace* w;
+  PVW_TRY(ws_for_stream(c, s, &w));
+  const u32 k = c->k, l = c->l, L = c->L;
+  const size_t P = c->poly();
+  // chunks of about 2 GiB of ciphertext (measured: at config 5 in full, 18 GB, overlapping the decode is -7 %;
+  // with 0.3 GB chunks the cross-stream events cost more than the decode they hide, +29 %): below 3 GiB in all,
+  // one pass on the caller's stream.  PVW_DECRYPT_CHUNK=<dealers> overrides.
+  static long chunk_env = [] { const char* e = getenv("PVW_DECRYPT_CHUNK"); return e ? atol(e) : 0L; }();
+  const double total_gib = (double)D * k * P * 8 / (double)((size_t)1 << 30);
+  size_t chunk = D;
+  if (chunk_env >= 64) chunk = (size_t)chunk_env;
+  else if (total_gib >= 3.0) chunk = (D + (size_t)(total_gib / 2.0) - 1) / (size_t)(total_gib / 2.0);
+  const size_t nch = (D + chunk - 1) / chunk;
+  {
+    ProfScope ps(c, "prep", s);
+    PVW_HIP(launch_prep(d_sk, nullptr, w->rhat, P, l, k, true, c->dt, L, l, s));   // NTT(sk[j]) once per call (secret_key.rs:98-112)
+  }
+  const bool overlap = nch >= 2;
+  if (overlap) {
+    if (!w->aux) PVW_HIP(hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking));
+    while (w->events.size() < nch + 1) {
+      hipEvent_t e;
+      PVW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      w->events.push_back(e);
+    }
+  }
+  for (size_t i = 0; i < nch; ++i) {
+    const size_t d0 = i * chunk, cnt = (D - d0) < chunk ? (D - d0) : chunk;
+    u64* nz = d_noisy + d0 * P;
+    {
+      ProfScope ps(c, "decrypt_mac", s);
+      PVW_HIP(launch_decrypt_mac(d_c1s + d0 * k * P, w->rhat, d_c2col + d0 * P, nz, c->dt, k, L, l, cnt, s));   // decryption.rs:257-274
+    }
+    {
+      ProfScope ps(c, "intt", s);
+      PVW_HIP(launch_ntt(nz, cnt, true, c->dt, L, l, s));                                                        // :116
+    }
+    hipStream_t ds = s;
+    if (overlap) {
+      PVW_HIP(hipEventRecord(w->events[i], s));
+      PVW_HIP(hipStreamWaitEvent(w->aux, w->events[i], 0));
+      ds = w->aux;
+    }
+    ProfScope ps(c, "decode", ds);
+    PVW_HIP(launch_decode(nz, d_out + d0, cnt, c->dec_dev, ds));                                                 // :10-58
+  }
+  if (overlap) {
+    PVW_HIP(hipEventRecord(w->events[nch], w->aux));
+    PVW_HIP(hipStreamWaitEvent(s, w->events[nch], 0));
+  }
+  return PVW_OK;
 }
 
 int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, const uint64_t* c2col, size_t D,

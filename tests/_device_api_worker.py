@@ -100,6 +100,12 @@ def main():
     vals, noisy = P.api._decrypt_batch(p, cts, P.SecretKey.from_coefficients(p, sk), 3, return_noisy=True)
     assert np.array_equal(d_noisy.cpu().numpy().view(np.uint64), noisy)
     assert [int(v) for v in d_vals.cpu().numpy().view(np.uint64)] == vals
+    # the one-call form (single chunk here)
+    d_noisy_b = torch.zeros_like(d_noisy)
+    d_vals_b = torch.zeros_like(d_vals)
+    P.api._check(lib.pvw_decrypt_batch_device(p._h, ptr(d_sk), ptr(d_c1s), ptr(d_c2col), D, P.REPR_NTT, ptr(d_noisy_b), ptr(d_vals_b), stream))
+    torch.cuda.synchronize()
+    assert torch.equal(d_noisy_b, d_noisy) and torch.equal(d_vals_b, d_vals)
     config5_full_size(lib, stream, dev)
     print("DEVICE_API_OK")
 
@@ -139,6 +145,13 @@ def config5_full_size(lib, stream, dev):
     for d, z in zip(pick, got):
         lifted = M.from_rns([[int(v) for v in row] for row in z], list(moduli))
         assert int(vals[d]) == M.decode_scalar_pvw(lifted, mp), "config-5 full size: decode"
+    # pvw_decrypt_batch_device: eight chunks of 1024 dealers, each decode on the helper stream under the next MAC
+    d_noisy_b = torch.zeros_like(d_noisy)
+    d_vals_b = torch.zeros_like(d_vals)
+    for _ in range(3):
+        P.api._check(lib.pvw_decrypt_batch_device(p._h, ptr(d_sk), ptr(d_c1s), ptr(d_c2col), D, P.REPR_NTT, ptr(d_noisy_b), ptr(d_vals_b), stream))
+    torch.cuda.synchronize()
+    assert torch.equal(d_noisy_b, d_noisy) and torch.equal(d_vals_b, d_vals), "config-5 full size: overlapped batch decrypt"
     # linearity over ALL dealers: delta added to every NTT slot of c2 is the constant polynomial delta, so the
     # noisy polynomial (power basis) loses delta in coefficient 0 and nothing elsewhere, limb-wise
     delta = 12345
