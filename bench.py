@@ -388,7 +388,10 @@ def bench_decrypt(args, world, rank, local_rank, dev):
     params.set_profiling(False)
     mac_ms, launches = kt["decrypt_mac"]
     avg_s = mac_ms / max(launches, 1) * 1e-3
-    alg_bytes = 8 * L * l * (D * k + D + D + k)      # c1s + c2col reads, noisy write, s-hat read
+    # c1s + c2col reads, noisy write, s-hat read; a large batch runs as several launches
+    # (chunks of dealers), each reading s-hat again: bytes per launch = that chunk's share
+    per_step = max(launches // max(args.steps, 1), 1)
+    alg_bytes = 8 * L * l * (D * k + D + D + k * per_step) // per_step
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     # host decode of the D noisy polynomials (decryption.rs:10-58), timed separately
     nz = noisy.cpu().numpy().view(np.uint64)
@@ -405,7 +408,8 @@ def bench_decrypt(args, world, rank, local_rank, dev):
                    "q_bits": int(params.q_total().bit_length())},
         "roofline": {"bound": "hbm", "kernel": "decrypt_mac_fw_kernel" if L * l // 2 >= 128 else "decrypt_mac_grouped_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6, "launches_timed": launches},
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
+                     "launches_per_step": per_step},
         "kernel_ms_per_step": {name: v[0] / max(args.steps, 1) for name, v in kt.items()},
         "host_decode_reference": {"seconds": t_dec, "ciphertexts": D,
                                   "note": "the same decode with host big integers (pvw_decode_host), outside the timed region",
