@@ -325,8 +325,8 @@ def bench_keygen(args, world, rank, local_rank, dev):
 
 def bench_decrypt(args, world, rank, local_rank, dev):
     """Batched decrypt_party_value (decryption.rs:249-278) of D dealer ciphertexts per GPU for one
-    secret key: dealers are sharded over the ranks, nothing is exchanged on the data path (the
-    D x u64 results would be all-gathered by the caller)."""
+    secret key: dealers are sharded over the ranks; the only exchange is the all-gather of the decoded
+    D x u64 shares at the end of every step (RCCL; N > 1 only)."""
     import numpy as np
     import torch
 
@@ -350,6 +350,8 @@ def bench_decrypt(args, world, rank, local_rank, dev):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     vals_dev = torch.zeros(D, dtype=torch.int64, device=dev)
+    # config 5's one exchange step: every rank ends up with all D x world decoded shares (8 bytes each)
+    gathered = torch.zeros(D * world, dtype=torch.int64, device=dev) if world > 1 else None
 
     def step():
         # inner products, INTT and gadget decode on the device: only D x u64 would leave the GPU
@@ -358,6 +360,9 @@ def bench_decrypt(args, world, rank, local_rank, dev):
                                           C.c_void_p(noisy.data_ptr()), C.c_void_p(vals_dev.data_ptr()), stream)
         if rc != 0:
             raise RuntimeError(_ffi.last_error())
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_gather(list(gathered.chunk(world)), vals_dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -405,7 +410,8 @@ def bench_decrypt(args, world, rank, local_rank, dev):
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": desc, "dealers_per_gpu": D, "k": k, "l": l, "rns_limbs": L,
-                   "q_bits": int(params.q_total().bit_length())},
+                   "q_bits": int(params.q_total().bit_length()),
+                   "sharding": f"dealer-sharded x{world}" + (", all-gather of D x u64 decoded shares per step" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": "decrypt_mac_fw_kernel" if L * l // 2 >= 128 else "decrypt_mac_grouped_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
