@@ -239,12 +239,31 @@ inline PvwCiphertext encrypt_party_shares(const std::vector<uint64_t>& shares, u
   if (shares.size() != gpk.params->n) throw PvwError(1, "Party must provide n shares");
   return encrypt(shares, gpk, seed);
 }
-// encrypt_all_party_shares (encryption.rs:253-286)
+// encrypt_all_party_shares (encryption.rs:253-286): ONE batched call for all dealers (pvw_encrypt_multi: the
+// dealers share passes over the public key; from 8 dealers up on the matrix cores), dealer d seeded with
+// dealer_seed(seed, d) -- the same ciphertexts as n separate encrypt_party_shares calls
 inline std::vector<PvwCiphertext> encrypt_all_party_shares(const std::vector<std::vector<uint64_t>>& all_shares,
-                                                           const GlobalPublicKey& gpk, const Seed& seed) {
-  if (all_shares.size() != gpk.params->n) throw PvwError(1, "Must provide shares for all parties");
+                                                           const GlobalPublicKey& gpk, const Seed& seed,
+                                                           uint32_t repr = PVW_REPR_NTT) {
+  const auto& p = gpk.params;
+  if (all_shares.size() != p->n) throw PvwError(1, "Must provide shares for all parties");
+  const size_t D = all_shares.size(), n = p->n, P = p->poly_words();
+  std::vector<uint64_t> scalars(D * n), c1(D * p->k * P), c2(D * n * P);
+  std::vector<uint8_t> seeds(D * 32);
+  for (size_t d = 0; d < D; ++d) {
+    if (all_shares[d].size() != n) throw PvwError(1, "Party must provide n shares");
+    std::copy(all_shares[d].begin(), all_shares[d].end(), scalars.begin() + d * n);
+    const Seed sd = dealer_seed(seed, (uint32_t)d);
+    std::copy(sd.begin(), sd.end(), seeds.begin() + d * 32);
+  }
+  check(pvw_encrypt_multi(p->ctx, scalars.data(), D, n, seeds.data(), c1.data(), c2.data(), repr));
   std::vector<PvwCiphertext> out;
-  for (uint32_t d = 0; d < all_shares.size(); ++d) out.push_back(encrypt_party_shares(all_shares[d], d, gpk, dealer_seed(seed, d)));
+  for (size_t d = 0; d < D; ++d) {
+    PvwCiphertext ct{std::vector<uint64_t>(c1.begin() + d * p->k * P, c1.begin() + (d + 1) * p->k * P),
+                     std::vector<uint64_t>(c2.begin() + d * n * P, c2.begin() + (d + 1) * n * P), p, repr};
+    ct.validate();
+    out.push_back(std::move(ct));
+  }
   return out;
 }
 // encrypt_broadcast (encryption.rs:292-296)

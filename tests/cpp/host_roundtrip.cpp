@@ -28,6 +28,11 @@ int main() {
     for (uint32_t d = 0; d < num_parties; ++d)
       for (uint32_t j = 1; j <= num_parties; ++j) all[d].push_back(d * 100 + j);
     auto cts = encrypt_all_party_shares(all, global_pk, seed);
+    // the batched call gives the ciphertexts of n separate per-dealer calls (encryption.rs:277-283)
+    for (uint32_t d = 0; d < num_parties; ++d) {
+      auto one = encrypt_party_shares(all[d], d, global_pk, dealer_seed(seed, d));
+      if (one.c1 != cts[d].c1 || one.c2 != cts[d].c2) { printf("batched/separate mismatch at dealer %u\n", d); return 1; }
+    }
     uint32_t correct = 0, total = 0;
     for (uint32_t i = 0; i < num_parties; ++i) {
       auto shares = decrypt_party_shares(cts, parties[i].secret_key, i);
