@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
   const u64* y = vhat + (size_t)v * vstride + (size_t)limb * k * ELL + slot;
   signed char* tiles = YD + (((size_t)vg * L + limb) * ELL + slot) * (size_t)JB * 1024;
   int colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  __shared__ v4i32 st[STAGE ? 64 * 16 : 1];                     // [tile of this pass][piece], 16 KiB
+  __shared__ v4i32 st[STAGE ? 32 * 16 : 1];                     // [tile of this round][piece], 8 KiB
   const u32 jb_end = STAGE ? ((JB + 63) & ~63u) : JB;           // STAGE: whole passes, every lane takes part in the staging
   for (u32 jb = lane; jb < jb_end; jb += 64) {
     // digit[b][kappa], kappa = 8*jj + a  (32 bytes per digit column b = four u64, one per jj)
@@ -1642,22 +1642,30 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
       // this lane's 16 runs of 16 bytes (piece = 8 h + b) go through LDS so that every global store
       // instruction writes whole 128-byte lines (lanes 8x..8x+7 = the 8 digit columns of one (tile, h)).
       // The piece index is XORed with the tile index so that neither side has bank conflicts.
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        st[lane * 16 + ((0 * 8 + b) ^ (lane & 15))] = dg.q[b][0];   // h = 0: kappa 0..15
-        st[lane * 16 + ((1 * 8 + b) ^ (lane & 15))] = dg.q[b][1];   // h = 1: kappa 16..31
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      // two rounds of 32 tiles each keep the staging buffer at 8 KiB per wave (20 waves per CU instead of 10)
       const u32 jb0 = jb - lane;                                   // first tile of this pass
+#pragma unroll
+      for (u32 rnd = 0; rnd < 2; ++rnd) {
+        __builtin_amdgcn_wave_barrier();
+        if ((lane >> 5) == rnd) {
+          const u32 tq = lane & 31;
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            st[tq * 16 + ((0 * 8 + b) ^ (tq & 15))] = dg.q[b][0];   // h = 0: kappa 0..15
+            st[tq * 16 + ((1 * 8 + b) ^ (tq & 15))] = dg.q[b][1];   // h = 1: kappa 16..31
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-      for (u32 it = 0; it < 16; ++it) {
-        const u32 tl = it * 4 + (lane >> 4), piece = lane & 15;
-        const v4i32 val = st[tl * 16 + (piece ^ (tl & 15))];
-        const u32 hh = piece >> 3, bb = piece & 7;
-        if (jb0 + tl < JB)
-          *reinterpret_cast<v4i32*>(tiles + (size_t)(jb0 + tl) * 1024 + (size_t)(hh * 32 + v4 * 8 + bb) * 16) = val;
+        for (u32 it = 0; it < 8; ++it) {
+          const u32 tl = it * 4 + (lane >> 4), piece = lane & 15;   // tile within the round
+          const v4i32 val = st[tl * 16 + (piece ^ (tl & 15))];
+          const u32 hh = piece >> 3, bb = piece & 7;
+          const u32 tg = jb0 + rnd * 32 + tl;
+          if (tg < JB)
+            *reinterpret_cast<v4i32*>(tiles + (size_t)tg * 1024 + (size_t)(hh * 32 + v4 * 8 + bb) * 16) = val;
+        }
       }
     } else {
       signed char* tile = tiles + (size_t)jb * 1024;
