@@ -1215,7 +1215,7 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
                                      size_t D, u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
   const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
   const size_t P = c->poly();
-  static int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 8; }();
+  const int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 3; }();   // read per call (tests switch it); measured at config 3: 2 dealers 0.23 ms on the VALU vs 0.25 here, 4 dealers 0.43 vs 0.26, 6 dealers 0.67 vs 0.31
   const bool use_gemm = gemm_min > 0 && D >= (size_t)gemm_min;
   if (use_gemm) {
     PVW_TRY(ws_gemm_buffers(c, w));
@@ -1647,7 +1647,7 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   hipStream_t s = w->stream;
   // >= 8 parties: the matrix cores (gemm_digits, 16 parties per pass over A^T, everything around it batched
   // over super-groups of up to 128 parties); fewer: 4 per pass on the VALU
-  static int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 8; }();
+  const int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 8; }();
   const bool use_gemm = gemm_min > 0 && (b - a) >= (u32)gemm_min;
   const u32 group = use_gemm ? 16 : 4;
   // super-group: parties whose sampling, NTTs, digit tiles and final tiling are single launches; bounded so

@@ -347,9 +347,12 @@ def test_decrypt_mac_launch_shapes_agree_with_c_oracle(k, l, L, D, monkeypatch):
         assert np.array_equal(noisy, want), (variant, c)
 
 
-@pytest.mark.parametrize("D", [1, 4, 7])
-def test_multi_dealer_encrypt_equals_separate_encrypts(D):
-    # encrypt_all_party_shares (encryption.rs:253-286) batched four dealers per pass over B-hat
+@pytest.mark.parametrize("D", [1, 2, 4, 7])
+@pytest.mark.parametrize("gemm_from", [0, 3])
+def test_multi_dealer_encrypt_equals_separate_encrypts(D, gemm_from, monkeypatch):
+    # encrypt_all_party_shares (encryption.rs:253-286): the integer-VALU form (four dealers per pass over B-hat;
+    # forced everywhere with PVW_GEMM_MIN_DEALERS=0) and the default split (matrix cores from 3 dealers up)
+    monkeypatch.setenv("PVW_GEMM_MIN_DEALERS", str(gemm_from))
     n, k, l, moduli = 13, 9, 8, M.bench_moduli(4)
     p = build_params(n, k, l, moduli)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
@@ -376,7 +379,7 @@ def test_multi_dealer_encrypt_equals_separate_encrypts(D):
     (40, 512, 16, 2, 17),     # k = 512: the 16-chunk unrolled form, one full batch + one dealer
 ])
 def test_digit_gemm_multi_dealer_equals_separate_encrypts(n, k, l, L, D):
-    # >= 8 dealers take the matrix-core path (gemm_digits_kernel): i8 MFMA over byte-folded operands
+    # >= 3 dealers take the matrix-core path (gemm_digits_kernel): i8 MFMA over byte-folded operands
     moduli = M.bench_moduli(L)
     p = build_params(n, k, l, moduli)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
