@@ -213,6 +213,12 @@ def main():
                      "launches_timed": mac_launches},
         "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},
     }
+    if Dm == 0:
+        # what the memory system gives this access pattern with the arithmetic removed (read-only probe over B-hat)
+        sec, nbytes = C.c_double(0.0), C.c_uint64(0)
+        if lib.pvw_selftest_read_bandwidth(h, 20, C.byref(sec), C.byref(nbytes)) == 0 and sec.value > 0:
+            out["roofline"]["read_probe"] = {"GBps": nbytes.value / sec.value / 1e9, "bytes_per_pass": nbytes.value,
+                                             "note": "same loads as mac_rows (1-KiB tiles, 16 B/lane, nt, 16 in flight per wave), xor instead of the modular MAC"}
     if Dm > 0:
         out["metric"] = ("party-ciphertexts/s for encrypt_all_party_shares (D dealers x n parties, "
                          + ("batches of 16, up to 64 per launch" if gemm_path else "4") + " dealers per pass over B-hat)")

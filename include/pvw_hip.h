@@ -242,6 +242,9 @@ PVW_API int32_t pvw_selftest_decode_fixed(const pvw_ctx* ctx, const uint64_t* no
 /* SELF-TEST: C[32][32] (int32) = A[32][32] * B[32][32] (int8, row-major) with one i8 MFMA fetched
  * through the lane maps the digit-GEMM kernels assume. */
 PVW_API int32_t pvw_selftest_mfma_i8(pvw_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* out);
+/* MEASUREMENT AID (bench.py): seconds per pass of a read-only kernel with the access pattern of the streamed
+ * inner products (crs.rs:188-201, encryption.rs:177-200) over the resident public-key section */
+PVW_API int32_t pvw_selftest_read_bandwidth(pvw_ctx* ctx, uint32_t reps, double* seconds_per_pass, uint64_t* bytes_per_pass);
 
 /* ---- ring primitives (fhe-math call sites) -----------------------
  * change_representation(Ntt / PowerBasis) on `count` polynomials, host buffers, in place */

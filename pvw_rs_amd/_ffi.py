@@ -80,6 +80,7 @@ _SIGNATURES = {
     "pvw_decode_device": [_P, _P, C.c_size_t, _P, _P],
     "pvw_selftest_decode_fixed": [_P, _P, C.c_size_t, _P],
     "pvw_selftest_mfma_i8": [_P, _P, _P, _P],
+    "pvw_selftest_read_bandwidth": [_P, C.c_uint32, _P, _P],
     "pvw_ntt_forward": [_P, _P, C.c_size_t],
     "pvw_ntt_inverse": [_P, _P, C.c_size_t],
     "pvw_small_to_poly": [_P, _P, C.c_size_t, _P, C.c_uint32],

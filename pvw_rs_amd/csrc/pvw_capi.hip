@@ -1408,6 +1408,36 @@ int32_t pvw_decode_host(const pvw_ctx* c, const uint64_t* noisy, size_t count, u
   return PVW_OK;
 }
 
+// MEASUREMENT AID: seconds per pass of a read-only kernel with mac_rows' access pattern over the resident public
+// key section (B-hat, tiled): what the memory system delivers to this pattern, next to what mac_rows achieves
+int32_t pvw_selftest_read_bandwidth(pvw_ctx* c, uint32_t reps, double* seconds_per_pass, uint64_t* bytes_per_pass) {
+  if (!c || !seconds_per_pass || !bytes_per_pass || reps == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(ensure_device(c));
+  if (!c->dB || c->rowsB() == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "no public key section resident");
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  const size_t tiles = c->tiled_words(c->rowsB()) / 128;
+  const u32 tpw = c->k >= 64 ? (c->k / 4 / 16) * 16 : 16;           // a workgroup covers k tiles, as in mac_rows
+  int32_t rc = ws_scratch(w, ((tiles + 63) / 64 + 1) * 8);
+  hipEvent_t a = nullptr, b = nullptr;
+  if (rc == PVW_OK && (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)) rc = fail(PVW_ERR_INTERNAL, "event");
+  if (rc == PVW_OK) {
+    bool ok = launch_read_probe(c->dB, tiles, tpw, (u64*)w->scratch, w->stream) == hipSuccess;   // warm-up
+    ok = ok && hipEventRecord(a, w->stream) == hipSuccess;
+    for (uint32_t i = 0; ok && i < reps; ++i) ok = launch_read_probe(c->dB, tiles, tpw, (u64*)w->scratch, w->stream) == hipSuccess;
+    ok = ok && hipEventRecord(b, w->stream) == hipSuccess && hipEventSynchronize(b) == hipSuccess;
+    float ms = 0;
+    ok = ok && hipEventElapsedTime(&ms, a, b) == hipSuccess;
+    if (!ok) rc = fail(PVW_ERR_INTERNAL, "read probe failed");
+    *seconds_per_pass = (double)ms * 1e-3 / reps;
+    *bytes_per_pass = (uint64_t)tiles * 1024;
+  }
+  if (a) hipEventDestroy(a);
+  if (b) hipEventDestroy(b);
+  ws_release(c, w);
+  return rc;
+}
+
 // SELF-TEST: one i8 MFMA through the operand maps the digit-GEMM kernels assume (exact integer data)
 int32_t pvw_selftest_mfma_i8(pvw_ctx* c, const int8_t* a, const int8_t* b, int32_t* out) {
   if (!c || !a || !b || !out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");

@@ -145,6 +145,8 @@ hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, i
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
                               hipStream_t s);
+// read-only probe: every wave streams `tiles` consecutive 1-KiB tiles (16 in flight), grid as mac_rows
+hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, hipStream_t s);
 hipError_t launch_mfma_probe(const signed char* A, const signed char* B, int* C, hipStream_t s);
 hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s);
 

@@ -1987,6 +1987,31 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
 }
 
 // ------------------------------------------------------------------------------------
+// read-bandwidth probe (self-test / measurement aid): the loads of mac_rows -- 1-KiB tiles, 16 bytes per lane,
+// non-temporal, 16 in flight per wave, four waves per workgroup on one contiguous run -- with the arithmetic
+// replaced by an xor, so that the ceiling the memory system offers this access pattern is measured, not assumed
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void read_probe_kernel(const u64* __restrict__ M, size_t total_tiles, u32 tiles_per_wave,
+                                                          u64* __restrict__ sink) {
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t run0 = (size_t)blockIdx.x * 4 * tiles_per_wave;          // the workgroup's contiguous run
+  const v2u64* p = reinterpret_cast<const v2u64*>(M) + lane;
+  v2u64 acc = (v2u64){0, 0};
+  // waves interleave groups of 16 tiles, as the default mac_rows schedule does
+  for (u32 g = 0; g + 16 <= tiles_per_wave; g += 16) {
+    v2u64 x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const size_t tile = run0 + (size_t)(g / 16) * 64 + wave * 16 + u;
+      x[u] = tile < total_tiles ? __builtin_nontemporal_load(p + tile * 64) : (v2u64){0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc ^= x[u];
+  }
+  if ((acc.x ^ acc.y) == 0x9e3779b97f4a7c15ULL) sink[blockIdx.x] = acc.x;   // keeps the loads alive
+}
+
+// ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
 #define PVW_DISPATCH_ELL(ell, ...)                       \
@@ -2348,6 +2373,14 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
     PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sb.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
                               sb, t.mods, L, nv, nv_pad, sb.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_b));
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, hipStream_t s) {
+  if (total_tiles == 0 || tiles_per_wave < 16) return hipErrorInvalidValue;
+  const size_t per_wg = (size_t)4 * tiles_per_wave;
+  const u32 blocks = (u32)((total_tiles + per_wg - 1) / per_wg);
+  read_probe_kernel<<<dim3(blocks), dim3(256), 0, s>>>(M, total_tiles, tiles_per_wave, sink);
   return hipGetLastError();
 }
 

@@ -683,3 +683,16 @@ def test_config4_full_size_sampled_rows_against_c_oracle():
         assert np.array_equal(ct.c2[lo:lo + rows], c2o), f"c2 rows {lo}.."
         if lo == 0:
             assert np.array_equal(ct.c1, c1o), "c1"
+
+
+def test_read_bandwidth_probe_runs():
+    # the measurement aid bench.py reports beside mac_rows (same loads, no arithmetic): runs and gives a sane rate
+    import ctypes as C
+    from pvw_rs_amd import _ffi
+    p = build_params(2048, 256, 8, M.bench_moduli(17))
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    sec, nbytes = C.c_double(0.0), C.c_uint64(0)
+    P.api._check(_ffi.lib().pvw_selftest_read_bandwidth(p._h, 5, C.byref(sec), C.byref(nbytes)))
+    assert nbytes.value == 2048 // 16 * 17 * 256 * 1024
+    assert 500.0 < nbytes.value / sec.value / 1e9 < 8000.0
