@@ -67,6 +67,13 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
   const v2u64* rp = reinterpret_cast<const v2u64*>(rhat + (size_t)limb * k * ELL);
   v2u64* lw = lds + wave * (JC * HALF);
 
+  // the addend of this lane's output (e1 / e2 + m*g, written by the prologue) is requested now by the wave that
+  // will write the result: at the end it would cost the workgroup one more exposed memory latency
+  const u32 out_row = rb * R + rho;
+  const size_t out_o = (((size_t)out_row * L + limb) * ELL) / 2 + sp;
+  v2u64 add_pf = (v2u64){0, 0};
+  if (wave == 0 && addend && out_row < nrows) add_pf = reinterpret_cast<const v2u64*>(addend)[out_o];
+
   Acc a0, a1;
   acc_zero(a0);
   acc_zero(a1);
@@ -161,8 +168,7 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
   lds[wave * 64 + lane] = part;
   __syncthreads();
   if (wave == 0) {
-    const u32 row = rb * R + rho;
-    if (row < nrows) {
+    if (out_row < nrows) {
       v2u64 s = lds[lane];
 #pragma unroll
       for (int w = 1; w < NW; ++w) {
@@ -170,13 +176,11 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
         s.x = addmod(s.x, t.x, m.q);
         s.y = addmod(s.y, t.y, m.q);
       }
-      const size_t o = (((size_t)row * L + limb) * ELL) / 2 + sp;
       if (addend) {
-        v2u64 e = reinterpret_cast<const v2u64*>(addend)[o];
-        s.x = addmod(s.x, e.x, m.q);
-        s.y = addmod(s.y, e.y, m.q);
+        s.x = addmod(s.x, add_pf.x, m.q);
+        s.y = addmod(s.y, add_pf.y, m.q);
       }
-      reinterpret_cast<v2u64*>(out)[o] = s;
+      reinterpret_cast<v2u64*>(out)[out_o] = s;
     }
   }
 }
