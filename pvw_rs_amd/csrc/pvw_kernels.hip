@@ -905,6 +905,9 @@ __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __
 // G = 64/rem' consecutive j at once (rem' = rem rounded up to a power of two): its loads are G
 // segments of rem' pairs, again (nearly) full width.  The grouped form above leaves 15 % (L*l/2 = 272)
 // to 47 % (68) of the lanes of its last wave idle on every load.  Two dealers per workgroup.
+// (88 VGPRs is a budget, not an accident: 13 of these waves and the 8 waves of a decode workgroup share a CU when
+// pvw_decrypt_batch_device overlaps the two; prefetching c2 at the top costs 12 registers, gains 1.5 % alone and
+// loses 20 % overlapped.)
 template <int DG, int UJ>
 __global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restrict__ c1s,
                                                                const u64* __restrict__ shat,
