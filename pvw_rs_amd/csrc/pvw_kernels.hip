@@ -2033,7 +2033,7 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const u64* __restrict__
 // PVW_MAC_VARIANT (debug/tuning): selects the streaming schedule of mac_rows for l = 8 / 16
 //   0 (default) by shape, see below | 17 U=8 (l=8) / 16 (l=16) double-buffered nt, not interleaved | 1 same, default cache policy | 2 U=4 dbuf nt | 3 U=16 dbuf nt
 //   4 U=16 single buffer nt | 5 U=8 single buffer nt | 6 U=16 single buffer, default policy
-//   7 continuous stream U=8 nt | 8 continuous stream U=16 nt | 9/10/11 waves interleave groups of U=8/16/4 tiles
+//   7 continuous stream U=8 nt | 8 continuous stream U=16 nt | 9/10/11 waves interleave groups of U=8/16/4 tiles | 18/19 interleaved, single buffer, U=16/8
 static int mac_variant() {   // read per launch: the parity tests walk the variants in one process
   const char* e = getenv("PVW_MAC_VARIANT");
   return e ? atoi(e) : 0;
@@ -2059,6 +2059,8 @@ static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacS
       case 14: if (k % 128 == 0) { mac_rows_kernel<E, 16, true, true, true, 8><<<grid, dim3(512), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
       case 15: if (k % 64 == 0) { mac_rows_kernel<E, 4, true, true, true, 16><<<grid, dim3(1024), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
       case 16: if (k % 64 == 0) { mac_rows_kernel<E, 8, true, false, true, 8><<<grid, dim3(512), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 18: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, false, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 19: if (k % 32 == 0) { mac_rows_kernel<E, 8, true, false, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
       default: break;
     }
   }

@@ -314,7 +314,7 @@ def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
     e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
     e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
     c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), np.array(scalars, dtype=np.uint64), r, e1, e2)
-    for variant in range(0, 18):
+    for variant in range(0, 20):
         monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
         ct = P.encrypt(scalars, gpk, SEED)
         assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
