@@ -1747,6 +1747,10 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
     live[r] = ((rt0 + r) * 32) < sec.nrows;              // wave-uniform
   }
   const v4i32* ybase = reinterpret_cast<const v4i32*>(YD);
+  // column sums of the digit tiles (the +128 correction of the epilogue), requested up front
+  int sy_pf[NVG];
+#pragma unroll
+  for (int g = 0; g < NVG; ++g) sy_pf[g] = SY[(((size_t)g * L + limb) * ELL + slot) * 32 + (lane & 31)];
   v16i32 acc[RPW][NVG];
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
@@ -1862,7 +1866,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 #pragma unroll
     for (int g = 0; g < NVG; ++g) {
       const u32 v = g * 4 + v4;
-      const int sy128 = 128 * SY[(((size_t)g * L + limb) * ELL + slot) * 32 + col];
+      const int sy128 = 128 * sy_pf[g];
       int x[16];
 #pragma unroll
       for (int tt = 0; tt < 16; ++tt) x[tt] = acc[r][g][tt] + sy128;          // |.| < 2^26
