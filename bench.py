@@ -221,7 +221,7 @@ def main():
                                              "note": "same loads as mac_rows (1-KiB tiles, 16 B/lane, nt, 16 in flight per wave), xor instead of the modular MAC"}
     if Dm > 0:
         out["metric"] = ("party-ciphertexts/s for encrypt_all_party_shares (D dealers x n parties, "
-                         + ("batches of 16, up to 64 per launch" if gemm_path else "4") + " dealers per pass over B-hat)")
+                         + ("batches of 16, up to 128 per launch" if gemm_path else "4") + " dealers per pass over B-hat)")
         out["unit"] = "party-ciphertexts/s"
         out["roofline"]["kernel"] = "gemm_digits_kernel (i8 MFMA)" if gemm_path else "mac_rows_multi_kernel"
         mm = L * l * (n_per * k + rows_a * k) * nv / mac_avg_s if mac_avg_s > 0 else 0.0

@@ -745,7 +745,7 @@ static int32_t load_rows_host(pvw_ctx* c, u64* M, u32 shard_lo, u32 shard_hi, u3
 static u32 gemm_vb() {
   static u32 v = [] {
     const char* e = getenv("PVW_GEMM_VB");
-    int x = e ? atoi(e) : 4;
+    int x = e ? atoi(e) : 8;
     return (u32)(x < 1 ? 1 : (x > 8 ? 8 : x));
   }();
   return v;
