@@ -377,10 +377,12 @@ def test_multi_dealer_encrypt_equals_separate_encrypts(D, gemm_from, monkeypatch
     (200, 256, 8, 17, 8),     # config-3 geometry (k=256, 17 limbs) at a small party count
     (100, 256, 8, 3, 40),     # k = 256: fully unrolled chunk loop, three batches (16 + 16 + 8) in one launch
     (40, 512, 16, 2, 17),     # k = 512: the 16-chunk unrolled form, one full batch + one dealer
+    (6, 24, 64, 2, 9),        # l = 64
+    (9, 8, 8, 3, 130),        # more dealers than one launch takes (128)
 ])
 def test_digit_gemm_multi_dealer_equals_separate_encrypts(n, k, l, L, D):
     # >= 3 dealers take the matrix-core path (gemm_digits_kernel): i8 MFMA over byte-folded operands
-    moduli = M.bench_moduli(L)
+    moduli = M.bench_moduli(L) if l <= 32 else primes_1mod(128, L)
     p = build_params(n, k, l, moduli)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
     gpk.fill_uniform(SEED)
