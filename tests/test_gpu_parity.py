@@ -548,7 +548,7 @@ def test_config4_geometry_keygen_encrypt_decrypt():
     assert got == [int(x) for x in scalars]
 
 
-@pytest.mark.parametrize("case", range(12))
+@pytest.mark.parametrize("case", range(int(os.environ.get("PVW_RANDOM_CASES", "12"))))   # soak: PVW_RANDOM_CASES=80
 def test_random_geometries_full_pipeline_against_c_oracle(case):
     # seeded random (n, k, l, L, D, variance, bounds): key generation, single- and multi-dealer encrypt, batched
     # decrypt and decode, each against the C restatement / the big-integer model -- the reference's own tests
