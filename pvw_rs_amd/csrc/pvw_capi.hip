@@ -1691,7 +1691,7 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
     sg = 16 * (u32)m;
   }
   // scratch: A in API layout [k][k][P] | A^T in API layout | A^T tiled or MFMA-tiled | sk,ek of one chunk |
-  //          rows of B for one super-group | gemm intermediate | (gemm) s-hat vectors, sampled e, digit tiles, column sums
+  //          rows of B for one super-group | gemm intermediate | (gemm) s-hat vectors, digit tiles, column sums
   const size_t b_api = ((size_t)k * k * P * 8 + 255) & ~(size_t)255;
   const size_t b_tt = ((use_gemm ? xm_words(k, k, L, l) : c->tiled_words(k)) * 8 + 255) & ~(size_t)255;
   u32 chunk = (b - a) < 1024 ? (b - a) : 1024;         // parties whose sk / ek are uploaded together
@@ -1700,10 +1700,9 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   const size_t b_row = ((size_t)sg * k * P * 8 + 255) & ~(size_t)255;
   const size_t b_tmp = use_gemm ? (((size_t)(sg / 16) * gemm_tmp_words(k, L, l) * 8 + 255) & ~(size_t)255) : 0;
   const size_t b_vh = use_gemm ? b_row : 0;
-  const size_t b_ec = use_gemm ? (((size_t)sg * k * l * 8 + 255) & ~(size_t)255) : 0;
   const size_t b_yd = use_gemm ? ((yd_bytes(sg, k, L, l) + 255) & ~(size_t)255) : 0;
   const size_t b_sy = use_gemm ? ((sy_bytes(sg, L, l) + 255) & ~(size_t)255) : 0;
-  int32_t rc = ws_scratch(w, 2 * b_api + b_tt + b_small + b_row + b_tmp + b_vh + b_ec + b_yd + b_sy);
+  int32_t rc = ws_scratch(w, 2 * b_api + b_tt + b_small + b_row + b_tmp + b_vh + b_yd + b_sy);
   if (rc == PVW_OK) {
     char* base = (char*)w->scratch;
     u64* d_api = (u64*)base;
@@ -1714,9 +1713,8 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
     u64* d_tmp = (u64*)(base + 2 * b_api + b_tt + b_small + b_row);
     char* gb0 = base + 2 * b_api + b_tt + b_small + b_row + b_tmp;
     u64* d_vh = (u64*)gb0;
-    i64* d_ec = (i64*)(gb0 + b_vh);
-    signed char* d_yd = (signed char*)(gb0 + b_vh + b_ec);
-    int* d_sy = (int*)(gb0 + b_vh + b_ec + b_yd);
+    signed char* d_yd = (signed char*)(gb0 + b_vh);
+    int* d_sy = (int*)(gb0 + b_vh + b_yd);
     // A -> API layout -> transpose polynomials (A^T[c][j] = A[j][c]) -> tiled / MFMA-tiled
     bool okk = launch_untile(c->dA, d_api, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
     okk = okk && launch_transpose_polys(d_api, d_apiT, k, (u32)P, s) == hipSuccess;
@@ -1739,17 +1737,25 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
       ProfScope ps(c, "keygen", s);
       bool ok2 = true;
       if (use_gemm) {
-        // e_p (public_key.rs:128-132): sampled or explicit coefficients -> NTT form in the row buffer [nv][k][P]
-        const i64* e_src = ek ? d_small + (size_t)(chunk + in_chunk) * k * l : d_ec;
-        if (!ek) {
-          SampleJob je{}, z{};
-          je.kind = SAMPLE_UNIFORM; je.domain = DOM_EKEY; je.index0 = p0 * k; je.count = nv * k; je.bound = c->b1;
-          ok2 = launch_sample(d_ec, make_key(seed), l, je, z, z, s) == hipSuccess;
+        // ONE prologue launch for the super-group: the (s, e) families of party p0 replicated over its nv parties.
+        // s-hat_p (secret_key.rs:98-112) goes to the vector layout [party][limb][j][slot]; e_p (public_key.rs:128-132),
+        // sampled or explicit, to NTT form in the row buffer [nv][k][P]
+        {
+          PrologueBatch pb{};
+          if (seed) pb.key[0] = make_key(seed);
+          PrologueJob& js = pb.job[0];
+          PrologueJob& je = pb.job[1];
+          js.sj.count = k; js.explicit_coeffs = d_small + (size_t)in_chunk * k * l;
+          js.out = d_vh; js.stride_poly = l; js.stride_limb = (size_t)k * l;
+          js.rep_coeffs = (size_t)k * l; js.rep_out = (size_t)k * P;
+          je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = p0 * k; je.sj.count = k; je.sj.bound = c->b1;
+          je.rep_index0 = k;
+          if (ek) { je.explicit_coeffs = d_small + (size_t)(chunk + in_chunk) * k * l; je.rep_coeffs = (size_t)k * l; }
+          je.out = d_row; je.stride_poly = P; je.stride_limb = l; je.rep_out = (size_t)k * P;
+          pb.njobs = 2;
+          pb.reps = nv;
+          ok2 = launch_prologue(pb, c->dt, L, l, s) == hipSuccess;
         }
-        ok2 = ok2 && launch_prep(e_src, nullptr, d_row, P, l, nv * k, true, c->dt, L, l, s) == hipSuccess;
-        // s-hat_p (secret_key.rs:98-112) in the vector layout [party][limb][j][slot]
-        ok2 = ok2 && launch_prep(d_small + (size_t)in_chunk * k * l, nullptr, d_vh, l, (size_t)k * l, nv * k, true, c->dt, L, l, s,
-                                 k, (size_t)k * P) == hipSuccess;
         ok2 = ok2 && launch_vec_digits(d_vh, (size_t)k * P, d_yd, d_sy, nv, k, L, l, c->dt, s) == hipSuccess;
         // all batches of 16 parties in one launch (crs.rs:152-168): they share A^T through L2
         GemmSection ga{d_tt, d_row, d_row, d_tmp, k, 0, 0}, gb{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
