@@ -1758,7 +1758,10 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
         }
         ok2 = ok2 && launch_vec_digits(d_vh, (size_t)k * P, d_yd, d_sy, nv, k, L, l, c->dt, s) == hipSuccess;
         // all batches of 16 parties in one launch (crs.rs:152-168): they share A^T through L2
+        // ... and the finish pass writes b_p = s_p*A + e_p straight into the tiled B-hat (no re-tiling launch)
         GemmSection ga{d_tt, d_row, d_row, d_tmp, k, 0, 0}, gb{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        ga.tiled_out = c->dB;
+        ga.tiled_row0 = p0 - c->party_lo;
         ok2 = ok2 && launch_gemm_digits(ga, gb, d_yd, d_sy, c->dt, k, L, l, nv, (size_t)k * P, 0, s) == hipSuccess;
       } else {
         u64* vh = w->rhat;
@@ -1782,8 +1785,8 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
         MultiVec mv{vh, (size_t)k * P, (size_t)k * P, 0, nv};
         ok2 = ok2 && launch_mac_rows_multi(sa, sb, mv, c->dt, k, L, l, s) == hipSuccess;
       }
-      // d_row is [nv][k polys][P] = nv rows of B in API layout -> tile into B
-      ok2 = ok2 && launch_tile(d_row, c->dB, nv, p0 - c->party_lo, k, L, l, false, c->dt, s) == hipSuccess;
+      // VALU path: d_row is [nv][k polys][P] = nv rows of B in API layout -> tile into B
+      if (!use_gemm) ok2 = ok2 && launch_tile(d_row, c->dB, nv, p0 - c->party_lo, k, L, l, false, c->dt, s) == hipSuccess;
       if (!ok2) rc = fail(PVW_ERR_KEY_GENERATION, "keygen launch failed");
     }
     if (rc == PVW_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");

@@ -127,6 +127,10 @@ struct GemmSection {
   u32 nrows;
   u32 rt_groups;       // filled in by the launcher
   size_t tmp_bstride;  // words of `tmp` per batch of 16 vectors (filled in by the launcher)
+  // key generation: the finish pass writes vector v, GEMM row c straight into the TILED public-key matrix as
+  // element (party tiled_row0 + v, column c) instead of out[] (which is then only the addend); NULL = API layout
+  u64* tiled_out = nullptr;
+  u32 tiled_row0 = 0;
 };
 inline size_t gemm_tmp_words(u32 rows, u32 L, u32 ell) {
   return (size_t)L * ell * 16 * (((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * PVW_GEMM_ROWS_PER_WG);

@@ -1991,8 +1991,16 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
       const u32 e = threadIdx.x + 256 * x;
       const u32 slot = e % ELL, row = e / ELL;
       if (e < 32 * ELL && row0 + row < sec.nrows && v0 + vi < nv) {
-        const size_t o = (size_t)(v0 + vi) * ostride + ((size_t)(row0 + row) * L + limb) * ELL + slot;
-        sec.out[o] = addmod(tile[vi][slot][row], add[vi][x], q);
+        const u64 val = addmod(tile[vi][slot][row], add[vi][x], q);
+        if (sec.tiled_out) {
+          // M[row_block][limb][j][rho][slot] with the party as the matrix row and the GEMM row as j
+          constexpr u32 R = 128 / ELL;
+          const u32 prow = sec.tiled_row0 + v0 + vi;
+          sec.tiled_out[(((size_t)(prow / R) * L + limb) * sec.nrows + (row0 + row)) * 128 + (prow % R) * ELL + slot] = val;
+        } else {
+          const size_t o = (size_t)(v0 + vi) * ostride + ((size_t)(row0 + row) * L + limb) * ELL + slot;
+          sec.out[o] = val;
+        }
       }
     }
 }
