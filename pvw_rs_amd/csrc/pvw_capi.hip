@@ -1660,6 +1660,73 @@ int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, co
 // mac_rows pass over the transposed CRS per party (public_key.rs:111-147, crs.rs:138-171).
 // The CRS is transposed once per call into a temporary tiled matrix; groups of 4 parties then
 // share one pass over it (mac_rows_multi with s-hat_i in the role of r-hat).
+// key generation on the matrix cores with the roles chosen so that the SHARED operand is digitised once:
+//   b_p[col] = sum_j s-hat_p[j] * A-hat[j][col] + e_p[col]
+// GEMM rows = parties (their s-hat rows are the raw streamed operand, MFMA-tiled per chunk), GEMM vectors = the k
+// columns of A-hat (digit tiles built ONCE per call, straight from the CRS in API layout: no transpose), the
+// finish pass adds e_p and writes into the tiled B-hat.  Chunks of up to 1024 parties.
+static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 lo, const int64_t* sk, const int64_t* ek,
+                                   const uint8_t* seed) {
+  const u32 k = c->k, l = c->l, L = c->L;
+  const size_t P = c->poly();
+  hipStream_t s = w->stream;
+  const u32 chunk = (b - a) < 1024 ? (b - a) : 1024;
+  const u32 nb = (k + 15) / 16;                                      // batches of 16 column-vectors
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t b_api = al((size_t)k * k * P * 8);
+  const size_t b_yd = al(yd_bytes(16 * nb, k, L, l)), b_sy = al(sy_bytes(16 * nb, L, l));   // whole batches: the last one is read in full
+  const size_t b_small = al((size_t)2 * chunk * k * l * 8);
+  const size_t b_rows = al((size_t)chunk * k * P * 8);                // s-hat rows | e rows, API layout [p][j or col][P]
+  const size_t b_xm = al(xm_words(chunk, k, L, l) * 8);
+  const size_t b_tmp = al((size_t)nb * gemm_tmp_words(chunk, L, l) * 8);
+  PVW_TRY(ws_scratch(w, b_api + b_yd + b_sy + b_small + 2 * b_rows + b_xm + b_tmp));
+  char* base = (char*)w->scratch;
+  u64* d_api = (u64*)base;
+  signed char* d_yd = (signed char*)(base + b_api);
+  int* d_sy = (int*)(base + b_api + b_yd);
+  i64* d_small = (i64*)(base + b_api + b_yd + b_sy);
+  u64* d_srow = (u64*)(base + b_api + b_yd + b_sy + b_small);
+  u64* d_erow = (u64*)(base + b_api + b_yd + b_sy + b_small + b_rows);
+  u64* d_xm = (u64*)(base + b_api + b_yd + b_sy + b_small + 2 * b_rows);
+  u64* d_tmp = (u64*)(base + b_api + b_yd + b_sy + b_small + 2 * b_rows + b_xm);
+  // A-hat -> API layout [j][col][limb][slot]; vector `col` is its column: element j at col * P + limb * l + j * (k * P)
+  PVW_HIP(launch_untile(c->dA, d_api, k, 0, k, L, l, false, c->dt, s));
+  PVW_HIP(launch_vec_digits(d_api, P, d_yd, d_sy, k, k, L, l, c->dt, s, l, (size_t)k * P));
+  for (u32 p0 = a; p0 < b; p0 += chunk) {
+    const u32 cnt = (b - p0) < chunk ? (b - p0) : chunk;
+    const size_t words = (size_t)cnt * k * l;
+    PVW_HIP(hipMemcpyAsync(d_small, sk + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s));
+    if (ek) PVW_HIP(hipMemcpyAsync(d_small + (size_t)chunk * k * l, ek + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s));
+    ProfScope ps(c, "keygen", s);
+    // one prologue launch: s-hat_p (secret_key.rs:98-112) and e_p (public_key.rs:128-132) as rows [p][.][limb][slot]
+    PrologueBatch pb{};
+    if (seed) pb.key[0] = make_key(seed);
+    PrologueJob& js = pb.job[0];
+    PrologueJob& je = pb.job[1];
+    js.sj.count = k; js.explicit_coeffs = d_small; js.rep_coeffs = (size_t)k * l;
+    js.out = d_srow; js.stride_poly = P; js.stride_limb = l; js.rep_out = (size_t)k * P;
+    je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = p0 * k; je.sj.count = k; je.sj.bound = c->b1;
+    je.rep_index0 = k;
+    if (ek) { je.explicit_coeffs = d_small + (size_t)chunk * k * l; je.rep_coeffs = (size_t)k * l; }
+    je.out = d_erow; je.stride_poly = P; je.stride_limb = l; je.rep_out = (size_t)k * P;
+    pb.njobs = 2;
+    pb.reps = cnt;
+    PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
+    // the chunk's s-hat rows -> MFMA-tiled raw operand (the kernel writes the padding itself for l <= 32)
+    if (l > 32) PVW_HIP(hipMemsetAsync(d_xm, 0, xm_words(cnt, k, L, l) * 8, s));
+    PVW_HIP(launch_mftile(d_srow, false, d_xm, cnt, k, L, l, s));
+    // all k columns in one launch (crs.rs:152-168); out / addend element (v = col, row = p) at p * k * P + col * P
+    GemmSection ga{d_xm, d_erow, d_erow, d_tmp, cnt, 0, 0}, gb{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    ga.tiled_out = c->dB;
+    ga.tiled_row0 = p0 - c->party_lo;
+    ga.tiled_swap = 1;
+    ga.row_stride = (size_t)k * P;
+    PVW_HIP(launch_gemm_digits(ga, gb, d_yd, d_sy, c->dt, k, L, l, k, P, 0, s));
+  }
+  PVW_HIP(hipStreamSynchronize(s));
+  return PVW_OK;
+}
+
 int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, const int64_t* ek, const uint8_t seed[32]) {
   if (!c || !sk) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   if (!ek && !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "either explicit key errors or a seed is required");
@@ -1679,6 +1746,15 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   // over super-groups of up to 128 parties); fewer: 4 per pass on the VALU
   const int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 8; }();
   const bool use_gemm = gemm_min > 0 && (b - a) >= (u32)gemm_min;
+  // default matrix-core form: parties as GEMM rows, the CRS columns digitised once (PVW_KEYGEN_SWAP=0: the earlier
+  // form with the transposed CRS as the streamed operand and the secret keys digitised per super-group)
+  const int swap_roles = [] { const char* e = getenv("PVW_KEYGEN_SWAP"); return e ? atoi(e) : 1; }();   // per call: the tests walk both
+  if (use_gemm && swap_roles && (b - a) >= 64) {
+    int32_t rc2 = keygen_gemm_swapped(c, w, a, b, lo, sk, ek, seed);
+    ws_release(c, w);
+    if (rc2 == PVW_OK && hi > c->num_keys) c->num_keys = hi;
+    return rc2;
+  }
   const u32 group = use_gemm ? 16 : 4;
   // super-group: parties whose sampling, NTTs, digit tiles and final tiling are single launches; bounded so
   // that the digit tiles stay below ~2 GiB

@@ -131,6 +131,10 @@ struct GemmSection {
   // element (party tiled_row0 + v, column c) instead of out[] (which is then only the addend); NULL = API layout
   u64* tiled_out = nullptr;
   u32 tiled_row0 = 0;
+  // tiled_swap: the GEMM ROW is the party (tiled_row0 + row) and the VECTOR the column instead
+  u32 tiled_swap = 0;
+  // element stride between consecutive GEMM rows in out / addend (0 = one polynomial, L * l)
+  size_t row_stride = 0;
 };
 inline size_t gemm_tmp_words(u32 rows, u32 L, u32 ell) {
   return (size_t)L * ell * 16 * (((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * PVW_GEMM_ROWS_PER_WG);
@@ -142,8 +146,10 @@ inline size_t xm_words(u32 rows, u32 k, u32 L, u32 ell) {
 inline size_t yd_bytes(u32 nv, u32 k, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) * L * ell * ((k + 3) / 4) * 1024; }
 inline size_t sy_bytes(u32 nv, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) * L * ell * 32 * sizeof(int); }
 hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s);
+// element j of vector v at (limb, slot): vhat[v * vstride + limb * lstride + j * jstride + slot];
+// lstride = jstride = 0 selects the r-hat layout [limb][j][slot] (lstride = k * l, jstride = l)
 hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
-                             const DevTables& t, hipStream_t s);
+                             const DevTables& t, hipStream_t s, size_t lstride = 0, size_t jstride = 0);
 // nv may exceed 16: batches of 16 vectors then run as extra workgroups of ONE launch (adjacent in dispatch
 // order, so they share the streamed matrix tiles through L2); tmp must hold ceil(nv/16) batches.
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,

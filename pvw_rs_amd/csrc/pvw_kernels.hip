@@ -1584,6 +1584,43 @@ __global__ __launch_bounds__(256) void mftile_kernel(const u64* __restrict__ src
   }
 }
 
+// the same from API-layout rows [row][j][limb][slot], through LDS: one block = (limb, row tile of 32, JBG j-blocks);
+// 64-byte runs in (the l slots of one (row, j)), whole 1-KiB tiles out; padding rows / j are written as the
+// offset-zero byte pattern, so XM needs no clearing beforehand.  (mftile_kernel scatters 8-byte words: 1.9 TB/s.)
+template <int ELL>
+__global__ __launch_bounds__(256) void mftile_rows_kernel(const u64* __restrict__ src, u64* __restrict__ XM, u32 rows, u32 k, u32 L) {
+  constexpr int JBG = ELL <= 8 ? 4 : (ELL == 16 ? 2 : 1);       // j-blocks (of 4 j) per block; LDS stays at 33 KB
+  constexpr int PLANE = JBG * 128 + 2;                          // u64 per slot plane (+2: bank spread)
+  __shared__ u64 lt[ELL * PLANE];
+  const u32 JB = (k + 3) / 4, JG = (JB + JBG - 1) / JBG;
+  const u32 RT = ((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * (PVW_GEMM_ROWS_PER_WG / 32);
+  const u32 jg = blockIdx.x % JG, rt = (blockIdx.x / JG) % RT, limb = blockIdx.x / (JG * RT);
+  const u32 row0 = rt * 32, j0 = jg * JBG * 4;
+  const size_t P = (size_t)L * ELL;
+  // in: pieces of 16 bytes (two slots): piece q = ((row * NJ + jj) * (ELL / 2) + sp)
+  constexpr int NJ = 4 * JBG, NPIECE = 32 * NJ * (ELL / 2);
+  for (int q = threadIdx.x; q < NPIECE; q += 256) {
+    const u32 sp = q % (ELL / 2), jj = (q / (ELL / 2)) % NJ, row = q / ((ELL / 2) * NJ);
+    v2u64 v = (v2u64){0, 0};
+    if (row0 + row < rows && j0 + jj < k)
+      v = *reinterpret_cast<const v2u64*>(src + ((size_t)(row0 + row) * k + (j0 + jj)) * P + (size_t)limb * ELL + 2 * sp);
+    const u32 jbl = jj >> 2, h = (jj >> 1) & 1, e = jj & 1;
+    const u32 w = (jbl * 64 + h * 32 + row) * 2 + e;
+    lt[(2 * sp) * PLANE + w] = v.x ^ 0x8080808080808080ULL;      // bytes stored signed-offset, as mftile_kernel does
+    lt[(2 * sp + 1) * PLANE + w] = v.y ^ 0x8080808080808080ULL;
+  }
+  __syncthreads();
+  // out: ELL * JBG tiles of 64 lanes x 16 bytes
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (u32 tq = wave; tq < ELL * JBG; tq += 4) {
+    const u32 slot = tq / JBG, jbl = tq % JBG;
+    if (jg * JBG + jbl >= JB) continue;
+    const v2u64 v = (v2u64){lt[slot * PLANE + (jbl * 64 + lane) * 2], lt[slot * PLANE + (jbl * 64 + lane) * 2 + 1]};
+    const size_t tile = (((size_t)limb * ELL + slot) * RT + rt) * JB + (jg * JBG + jbl);
+    *reinterpret_cast<v2u64*>(XM + tile * 128 + lane * 2) = v;
+  }
+}
+
 // vector elements -> digit tiles YD[vg][limb][slot][jb][h*32+col][16] and column sums SY.
 // One wave per (v, limb, slot); lane = j-block: each lane turns 4 consecutive j into the 8 shifted
 // copies y*2^(8a) mod q, writes their balanced digits as 16 16-byte runs, and the column sums are
@@ -1600,7 +1637,7 @@ __device__ __forceinline__ void transpose4x4_bytes(u32 x0, u32 x1, u32 x2, u32 x
 template <int ELL, bool STAGE>
 __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ vhat, size_t vstride,
                                                          signed char* __restrict__ YD, int* __restrict__ SY,
-                                                         u32 nv, u32 k, u32 L, DevTables t) {
+                                                         u32 nv, u32 k, u32 L, DevTables t, size_t lstride, size_t jstride) {
   const u32 lane = threadIdx.x;
   const u32 slot = blockIdx.x % ELL;
   const u32 limb = (blockIdx.x / ELL) % L;
@@ -1609,7 +1646,7 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
   const u32 JB = (k + 3) / 4;
   const u32 vg = v >> 2, v4 = v & 3;
   const u64 w256p = (m.ratio_hi << 8) | (m.ratio_lo >> 56);   // floor(256 * 2^64 / q) = floor(2^128 / q) >> 56
-  const u64* y = vhat + (size_t)v * vstride + (size_t)limb * k * ELL + slot;
+  const u64* y = vhat + (size_t)v * vstride + (size_t)limb * lstride + slot;
   signed char* tiles = YD + (((size_t)vg * L + limb) * ELL + slot) * (size_t)JB * 1024;
   int colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   __shared__ v4i32 st[STAGE ? 32 * 16 : 1];                     // [tile of this round][piece], 8 KiB
@@ -1620,7 +1657,7 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const u32 j = 4 * jb + jj;
-      u64 cur = j < k ? y[(size_t)j * ELL] : 0;
+      u64 cur = j < k ? y[(size_t)j * jstride] : 0;
       // the 8 balanced base-256 digits of w < 2^62 are the bytes of (w + 0x80..80) with their top bits
       // flipped: adding 128 to every byte position propagates exactly the carries of "digit > 127"
       const u64 C = 0x8080808080808080ULL;
@@ -1973,6 +2010,7 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
   const u64 q = mods[limb].q;
   u64 add[VPB][PT];
   const bool has_add = sec.addend != nullptr;
+  const size_t rstride = sec.row_stride ? sec.row_stride : (size_t)L * ELL;
 #pragma unroll
   for (int vi = 0; vi < VPB; ++vi)
 #pragma unroll
@@ -1981,7 +2019,7 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
       const u32 slot = e % ELL, row = (e / ELL) & 31;
       const u32 v = (v0 + vi) < nv ? (v0 + vi) : (nv - 1);
       const u32 rr = (row0 + row) < sec.nrows ? (row0 + row) : 0;
-      const size_t o = (size_t)v * ostride + ((size_t)rr * L + limb) * ELL + slot;
+      const size_t o = (size_t)v * ostride + (size_t)rr * rstride + (size_t)limb * ELL + slot;
       add[vi][x] = has_add ? sec.addend[o] : 0;
     }
 #pragma unroll
@@ -1995,10 +2033,12 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
         if (sec.tiled_out) {
           // M[row_block][limb][j][rho][slot] with the party as the matrix row and the GEMM row as j
           constexpr u32 R = 128 / ELL;
-          const u32 prow = sec.tiled_row0 + v0 + vi;
-          sec.tiled_out[(((size_t)(prow / R) * L + limb) * sec.nrows + (row0 + row)) * 128 + (prow % R) * ELL + slot] = val;
+          const u32 prow = sec.tiled_row0 + (sec.tiled_swap ? row0 + row : v0 + vi);     // party
+          const u32 pcol = sec.tiled_swap ? v0 + vi : row0 + row;                        // column of B
+          const u32 ncol = sec.tiled_swap ? nv : sec.nrows;
+          sec.tiled_out[(((size_t)(prow / R) * L + limb) * ncol + pcol) * 128 + (prow % R) * ELL + slot] = val;
         } else {
-          const size_t o = (size_t)(v0 + vi) * ostride + ((size_t)(row0 + row) * L + limb) * ELL + slot;
+          const size_t o = (size_t)(v0 + vi) * ostride + (size_t)(row0 + row) * rstride + (size_t)limb * ELL + slot;
           sec.out[o] = val;
         }
       }
@@ -2330,14 +2370,26 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
 
 hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s) {
   if (rows == 0) return hipSuccess;
+  if (!src_is_tiled && ell <= 32) {      // API-layout rows: the LDS-transposing form (writes every tile, padding included)
+    const u32 jbg = ell <= 8 ? 4 : (ell == 16 ? 2 : 1);
+    const u32 JB = (k + 3) / 4, JG = (JB + jbg - 1) / jbg;
+    const u32 RT = ((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * (PVW_GEMM_ROWS_PER_WG / 32);
+    switch (ell) {
+      case 8: mftile_rows_kernel<8><<<dim3(JG * RT * L), dim3(256), 0, s>>>(src, XM, rows, k, L); break;
+      case 16: mftile_rows_kernel<16><<<dim3(JG * RT * L), dim3(256), 0, s>>>(src, XM, rows, k, L); break;
+      default: mftile_rows_kernel<32><<<dim3(JG * RT * L), dim3(256), 0, s>>>(src, XM, rows, k, L); break;
+    }
+    return hipGetLastError();
+  }
   const size_t threads = (size_t)rows * k * L;
   PVW_DISPATCH_ELL(ell, mftile_kernel<E><<<dim3((u32)((threads + 255) / 256)), dim3(256), 0, s>>>(src, src_is_tiled ? 1u : 0u, XM, rows, k, L));
   return hipGetLastError();
 }
 
 hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
-                             const DevTables& t, hipStream_t s) {
+                             const DevTables& t, hipStream_t s, size_t lstride, size_t jstride) {
   if (nv == 0) return hipSuccess;
+  if (lstride == 0 && jstride == 0) { lstride = (size_t)k * ell; jstride = ell; }
   // unused vector slots of the last group must read as zero digits / zero sums
   if (nv % 4) {
     const u32 NVG = (nv + 3) / 4, JB = (k + 3) / 4;
@@ -2348,8 +2400,8 @@ hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, i
   }
   // default: stores staged through LDS (whole 128-byte lines per instruction, 16 KiB per wave); PVW_VEC_DIGITS_STAGE=0: direct
   static int stage = [] { const char* e = getenv("PVW_VEC_DIGITS_STAGE"); return e ? atoi(e) : 1; }();
-  if (stage) { PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, true><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t)); }
-  else { PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, false><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t)); }
+  if (stage) { PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, true><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t, lstride, jstride)); }
+  else { PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, false><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t, lstride, jstride)); }
   return hipGetLastError();
 }
 

@@ -608,11 +608,13 @@ def test_random_geometries_full_pipeline_against_c_oracle(case):
             assert sum(v == rows[d][i] for d, v in enumerate(vals)) >= 0.95 * D - 1
 
 
-def test_batched_keygen_super_groups_against_c_oracle():
-    # pvw_keygen over more than one super-group of 128 parties (public_key.rs:111-147, crs.rs:138-171) at
-    # k = 256: sampling, NTTs, digit extraction, ONE gemm launch per super-group, re-tiling -- against the C
-    # restatement, with seeded and with explicit key errors
-    n, k, l, L = 150, 256, 8, 2
+@pytest.mark.parametrize("swap,n,k,l,L", [(1, 150, 256, 8, 2), (0, 150, 256, 8, 2), (1, 70, 9, 8, 3), (1, 1100, 32, 16, 2)])
+def test_batched_keygen_super_groups_against_c_oracle(swap, n, k, l, L, monkeypatch):
+    # pvw_keygen on the matrix cores (public_key.rs:111-147, crs.rs:138-171) against the C restatement, with seeded
+    # and with explicit key errors.  swap = 1 (default): parties are the GEMM rows and the CRS columns are
+    # digitised once per call (also: ragged k, more than one 1024-party chunk); swap = 0: the transposed CRS is
+    # the streamed operand and super-groups of 128 secret keys are digitised
+    monkeypatch.setenv("PVW_KEYGEN_SWAP", str(swap))
     moduli = M.bench_moduli(L)
     p = build_params(n, k, l, moduli)
     seed = bytes([0x5A]) * 32
