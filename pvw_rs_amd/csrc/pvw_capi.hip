@@ -1675,28 +1675,45 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t b_api = al((size_t)k * k * P * 8);
   const size_t b_yd = al(yd_bytes(16 * nb, k, L, l)), b_sy = al(sy_bytes(16 * nb, L, l));   // whole batches: the last one is read in full
-  const size_t b_small = al((size_t)2 * chunk * k * l * 8);
+  const size_t b_small = al((size_t)2 * chunk * k * l * 8);                     // sk | ek of one chunk; two of these (double buffer)
   const size_t b_rows = al((size_t)chunk * k * P * 8);                // s-hat rows | e rows, API layout [p][j or col][P]
   const size_t b_xm = al(xm_words(chunk, k, L, l) * 8);
   const size_t b_tmp = al((size_t)nb * gemm_tmp_words(chunk, L, l) * 8);
-  PVW_TRY(ws_scratch(w, b_api + b_yd + b_sy + b_small + 2 * b_rows + b_xm + b_tmp));
+  PVW_TRY(ws_scratch(w, b_api + b_yd + b_sy + 2 * b_small + 2 * b_rows + b_xm + b_tmp));
   char* base = (char*)w->scratch;
   u64* d_api = (u64*)base;
   signed char* d_yd = (signed char*)(base + b_api);
   int* d_sy = (int*)(base + b_api + b_yd);
-  i64* d_small = (i64*)(base + b_api + b_yd + b_sy);
-  u64* d_srow = (u64*)(base + b_api + b_yd + b_sy + b_small);
-  u64* d_erow = (u64*)(base + b_api + b_yd + b_sy + b_small + b_rows);
-  u64* d_xm = (u64*)(base + b_api + b_yd + b_sy + b_small + 2 * b_rows);
-  u64* d_tmp = (u64*)(base + b_api + b_yd + b_sy + b_small + 2 * b_rows + b_xm);
+  i64* d_small2[2] = {(i64*)(base + b_api + b_yd + b_sy), (i64*)(base + b_api + b_yd + b_sy + b_small)};
+  u64* d_srow = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small);
+  u64* d_erow = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + b_rows);
+  u64* d_xm = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + 2 * b_rows);
+  u64* d_tmp = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + 2 * b_rows + b_xm);
+  // the secret keys of chunk i+1 are uploaded on a helper stream while chunk i computes
+  const u32 nchunks = (b - a + chunk - 1) / chunk;
+  if (!w->aux) PVW_HIP(hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking));
+  while (w->events.size() < 2 * (size_t)nchunks + 2) {
+    hipEvent_t e;
+    PVW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    w->events.push_back(e);
+  }
+  auto upload = [&](u32 ci, hipStream_t st) -> int32_t {
+    const u32 q0 = a + ci * chunk, cn = (b - q0) < chunk ? (b - q0) : chunk;
+    const size_t wd = (size_t)cn * k * l;
+    i64* dst = d_small2[ci & 1];
+    PVW_HIP(hipMemcpyAsync(dst, sk + (size_t)(q0 - lo) * k * l, wd * 8, hipMemcpyHostToDevice, st));
+    if (ek) PVW_HIP(hipMemcpyAsync(dst + (size_t)chunk * k * l, ek + (size_t)(q0 - lo) * k * l, wd * 8, hipMemcpyHostToDevice, st));
+    return PVW_OK;
+  };
+  PVW_TRY(upload(0, s));
   // A-hat -> API layout [j][col][limb][slot]; vector `col` is its column: element j at col * P + limb * l + j * (k * P)
   PVW_HIP(launch_untile(c->dA, d_api, k, 0, k, L, l, false, c->dt, s));
   PVW_HIP(launch_vec_digits(d_api, P, d_yd, d_sy, k, k, L, l, c->dt, s, l, (size_t)k * P));
-  for (u32 p0 = a; p0 < b; p0 += chunk) {
+  for (u32 ci = 0; ci < nchunks; ++ci) {
+    const u32 p0 = a + ci * chunk;
     const u32 cnt = (b - p0) < chunk ? (b - p0) : chunk;
-    const size_t words = (size_t)cnt * k * l;
-    PVW_HIP(hipMemcpyAsync(d_small, sk + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s));
-    if (ek) PVW_HIP(hipMemcpyAsync(d_small + (size_t)chunk * k * l, ek + (size_t)(p0 - lo) * k * l, words * 8, hipMemcpyHostToDevice, s));
+    i64* d_small = d_small2[ci & 1];
+    if (ci > 0) PVW_HIP(hipStreamWaitEvent(s, w->events[2 * ci], 0));          // this chunk's keys have arrived
     ProfScope ps(c, "keygen", s);
     // one prologue launch: s-hat_p (secret_key.rs:98-112) and e_p (public_key.rs:128-132) as rows [p][.][limb][slot]
     PrologueBatch pb{};
@@ -1712,6 +1729,7 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
     pb.njobs = 2;
     pb.reps = cnt;
     PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
+    PVW_HIP(hipEventRecord(w->events[2 * ci + 1], s));                         // this chunk's key buffer is free again
     // the chunk's s-hat rows -> MFMA-tiled raw operand (the kernel writes the padding itself for l <= 32)
     if (l > 32) PVW_HIP(hipMemsetAsync(d_xm, 0, xm_words(cnt, k, L, l) * 8, s));
     PVW_HIP(launch_mftile(d_srow, false, d_xm, cnt, k, L, l, s));
@@ -1722,6 +1740,13 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
     ga.tiled_swap = 1;
     ga.row_stride = (size_t)k * P;
     PVW_HIP(launch_gemm_digits(ga, gb, d_yd, d_sy, c->dt, k, L, l, k, P, 0, s));
+    if (ci + 1 < nchunks) {
+      // issued after this chunk's launches so that the host-side staging of a pageable copy overlaps the GPU's work;
+      // the buffer of chunk i+1 was last read by the prologue of chunk i-1
+      if (ci >= 1) PVW_HIP(hipStreamWaitEvent(w->aux, w->events[2 * (ci - 1) + 1], 0));
+      PVW_TRY(upload(ci + 1, w->aux));
+      PVW_HIP(hipEventRecord(w->events[2 * ci + 2], w->aux));
+    }
   }
   PVW_HIP(hipStreamSynchronize(s));
   return PVW_OK;

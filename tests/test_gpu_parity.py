@@ -608,7 +608,8 @@ def test_random_geometries_full_pipeline_against_c_oracle(case):
             assert sum(v == rows[d][i] for d, v in enumerate(vals)) >= 0.95 * D - 1
 
 
-@pytest.mark.parametrize("swap,n,k,l,L", [(1, 150, 256, 8, 2), (0, 150, 256, 8, 2), (1, 70, 9, 8, 3), (1, 1100, 32, 16, 2)])
+@pytest.mark.parametrize("swap,n,k,l,L", [(1, 150, 256, 8, 2), (0, 150, 256, 8, 2), (1, 70, 9, 8, 3), (1, 1100, 32, 16, 2),
+                                                 (1, 3100, 8, 8, 2)])    # four 1024-party chunks: both key buffers reused
 def test_batched_keygen_super_groups_against_c_oracle(swap, n, k, l, L, monkeypatch):
     # pvw_keygen on the matrix cores (public_key.rs:111-147, crs.rs:138-171) against the C restatement, with seeded
     # and with explicit key errors.  swap = 1 (default): parties are the GEMM rows and the CRS columns are
