@@ -6,10 +6,13 @@ dominant kernel (mac_rows) and the CPU restatement timed beside it.
 
 A "step" is one full encrypt (sample r/e1/e2 from a seed, NTT, c1 = A r + e1,
 c2 = B r + e2 + m g; src/crypto/encryption.rs:105-214) over synthetic A-hat / B-hat that are
-already resident in HBM.  N > 1 (launched by torch.distributed.run, one rank per GPU): the
-parties are sharded over the ranks (weak scaling: every rank holds the per-GPU party count),
-A-hat is broadcast once over RCCL at load time, and there is no collective on the data path.
-Rank 0 prints ONE JSON line.
+already resident in HBM.  N > 1: one rank per GPU -- either under torch.distributed.run, or started
+as `python bench.py --gpus N`, which launches torch.distributed.run itself as a child process before
+anything touches the GPU.  The parties are sharded over the ranks (weak scaling: every rank holds the
+per-GPU party count; `--config c4shard` / `--path decrypt --config c5shard` are BASELINE configs[3] /
+[4] as their 8-GPU shards), A-hat is broadcast once over RCCL at load time, and there is no collective
+on the data path.  Rank 0 prints ONE JSON line.  The workload definition (geometries, modulus chain,
+seeds) is pvw_rs_amd/workloads.py; oracle/ is touched by the cpu_baseline leg only.
 """
 import argparse
 import ctypes as C
@@ -19,27 +22,34 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-CONFIGS = {
-    # name: (n per GPU, k, l, limbs, description)
-    "c1": (16, 256, 8, 17, "BASELINE configs[0]: n=16, k=256, l=8, 1037-bit q (plumbing)"),
-    "c2": (1024, 256, 8, 17, "BASELINE configs[1]: n=1024, k=256, l=8, 1037-bit q"),
-    "c3": (4096, 256, 8, 17, "BASELINE configs[2] / north-star target: n=4096, k=256, l=8, 1037-bit q (17 limbs)"),
-    "c3x4": (16384, 256, 8, 17, "sizing experiment: config 3 geometry with n=16384 parties on one GPU"),
-    "c4full": (16384, 512, 16, 34, "BASELINE configs[3] in full on ONE GPU: n=16384, k=512, l=16, 2074-bit q (B-hat 36.5 GB)"),
-    "c4shard": (2048, 512, 16, 34, "BASELINE configs[3] per-GPU shard: n=16384/8, k=512, l=16, 2074-bit q"),
-}
-DECRYPT_CONFIGS = {
-    # name: (dealers per GPU, k, l, limbs, description)
-    "c5shard": (1024, 512, 16, 34, "BASELINE configs[4] per-GPU shard: D=8192/8 dealer ciphertexts, k=512, l=16, 2074-bit q"),
-    "c5full": (8192, 512, 16, 34, "BASELINE configs[4] in full on ONE GPU: D=8192 dealer ciphertexts, k=512, l=16, 2074-bit q (18.3 GB)"),
-    "d3": (2048, 256, 8, 17, "decrypt of D=2048 dealer ciphertexts at the config-3 geometry: k=256, l=8, 1037-bit q"),
-}
+from pvw_rs_amd import workloads as W          # noqa: E402  (pure Python: geometries, modulus chain, seeds)
+
+CONFIGS = W.ENCRYPT_CONFIGS
+DECRYPT_CONFIGS = W.DECRYPT_CONFIGS
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SEED_A, SEED_B, SEED_ENC = bytes([0xA]) * 32, bytes([0xB]) * 32, bytes([0x2A]) * 32
+SEED_A, SEED_B, SEED_ENC = W.SEED_A, W.SEED_B, W.SEED_ENC
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start torch.distributed.run as a CHILD process
+    (one rank per GPU, 127.0.0.1 rendezvous) before anything here has touched the GPU, and exit with its
+    code.  Under a launcher (WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def measured_traffic(config, kernel_prefix):
@@ -70,30 +80,34 @@ def main():
                     help="encrypt = the headline metric; decrypt = batched decrypt_party_value (BASELINE configs[4] shape)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-probe", action="store_true", help="skip the read-only bandwidth probe (tuning build)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="length of the back-to-back leg reported as `sustained` (0 = skip)")
     args = ap.parse_args()
+    self_launch(args)
 
     import numpy as np
     import torch
 
-    import pvw_model as M
     import pvw_rs_amd as P
     from pvw_rs_amd import _ffi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available() or not P.device_available():
+        print("bench.py needs a gfx950 GPU: the PVW hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ("nccl") over xGMI in production; PVW_BENCH_BACKEND=gloo only to rehearse the N>1 code path
         # on a box with fewer GPUs than ranks (see PVW_BENCH_SAME_DEVICE below)
         dist.init_process_group(backend=os.environ.get("PVW_BENCH_BACKEND", "nccl"))
-    if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
-        print("bench.py: --gpus > 1 must be launched with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    if not torch.cuda.is_available() or not P.device_available():
-        print("bench.py needs a gfx950 GPU: the PVW hot path has no CPU fallback", file=sys.stderr)
-        sys.exit(3)
     if os.environ.get("PVW_BENCH_SAME_DEVICE") == "1":
         local_rank = 0                     # rehearsal: every rank on cuda:0
     torch.cuda.set_device(local_rank)
@@ -105,11 +119,11 @@ def main():
         return bench_keygen(args, world, rank, local_rank, dev)
     n_per, k, l, L, desc = CONFIGS[args.config or "c3"]
     n_total = n_per * world
-    moduli = M.bench_moduli(L)
+    moduli = W.bench_moduli(L)
     from pvw_rs_amd import dist as D
     lo, hi, clo, chi = D.shard_ranges(n_total, k, world, rank)
     params = D.sharded_builder(n_total, k, l, moduli, world, rank, device=local_rank) \
-        .set_secret_variance(0.5).set_error_bounds_u32(100, 200).build()
+        .set_secret_variance(W.SECRET_VARIANCE).set_error_bounds_u32(W.ERROR_BOUND_1, W.ERROR_BOUND_2).build()
     h = params._h
     lib = _ffi.lib()
 
@@ -129,7 +143,7 @@ def main():
     gpk = P.GlobalPublicKey.new(crs)
     gpk.fill_uniform(SEED_B)
 
-    scalars = torch.tensor([(i * 1000 + 1) % (1 << 32) for i in range(n_total)], dtype=torch.int64, device=dev)
+    scalars = torch.tensor(W.scalars(n_total), dtype=torch.int64, device=dev)
     c1 = torch.zeros((chi - clo, L, l), dtype=torch.int64, device=dev)
     c2 = torch.zeros((n_per, L, l), dtype=torch.int64, device=dev)
     rnd = _ffi.pvw_randomness_t()
@@ -205,7 +219,8 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": desc, "parties_per_gpu": n_per, "parties_total": n_total, "k": k, "l": l,
                    "rns_limbs": L, "q_bits": int(params.q_total().bit_length()), "randomness": "seed (ChaCha8), on device", "dealers_per_step": max(Dm, 1),
-                   "sharding": f"party-sharded x{world}, A-hat broadcast once, no data-path collective"},
+                   "sharding": f"party-sharded x{world}, A-hat broadcast once, no data-path collective",
+                   "world_size_observed": world, "backend": (os.environ.get("PVW_BENCH_BACKEND", "nccl") if world > 1 else None)},
         "roofline": {"bound": "hbm", "kernel": "mac_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                      "traffic_source": (tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)") if tr else None,
@@ -213,16 +228,60 @@ def main():
                      "launches_timed": mac_launches},
         "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},
     }
-    if Dm == 0:
-        # what the memory system gives this access pattern with the arithmetic removed (read-only probe over B-hat)
-        sec, nbytes = C.c_double(0.0), C.c_uint64(0)
-        if lib.pvw_selftest_read_bandwidth(h, 20, C.byref(sec), C.byref(nbytes)) == 0 and sec.value > 0:
-            out["roofline"]["read_probe"] = {"GBps": nbytes.value / sec.value / 1e9, "bytes_per_pass": nbytes.value,
-                                             "note": "same loads as mac_rows (1-KiB tiles, 16 B/lane, nt, 16 in flight per wave), xor instead of the modular MAC"}
+    # ---- sustained leg: >= --sustain-seconds of back-to-back steps (clocks and thermals settle; the driver's
+    # gpu_busy sampler sees the GPU), then a profiled stretch of the same loop while the chip is still hot ----
+    if args.sustain_seconds > 0:
+        per_sync = 256
+        barrier()
+        t_s, n_s = time.perf_counter(), 0
+        while True:
+            for _ in range(per_sync):
+                step()
+            torch.cuda.synchronize()
+            n_s += per_sync
+            if time.perf_counter() - t_s >= args.sustain_seconds:
+                break
+        el_s = time.perf_counter() - t_s
+        params.set_profiling(True)
+        params.reset_profiling()
+        for _ in range(per_sync):
+            step()
+        torch.cuda.synchronize()
+        hot = params.kernel_time("gemm_digits" if gemm_path else ("mac_rows_multi" if Dm > 0 else "mac_rows"))
+        params.set_profiling(False)
+        hot_us = hot[0] / max(hot[1], 1) * 1e3
+        out["sustained"] = {"seconds": el_s, "steps": n_s, "value": n_total * max(Dm, 1) * n_s / el_s, "unit": out["unit"],
+                            "ms_per_step": el_s / n_s * 1e3, "dominant_kernel_avg_us_hot": hot_us,
+                            "roofline_frac_hot": (alg_bytes / (hot_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if hot_us > 0 and not gemm_path else None,
+                            "note": f"rank 0's own clock, synchronised every {per_sync} steps; not the contract's timed region"}
+    if Dm == 0 and rank == 0 and world == 1 and not args.no_probe:
+        # what the memory system gives this access pattern with the arithmetic removed (read-only probe over an
+        # identical B-hat).  The probe lives in the measurement build only (include/pvw_hip_tuning.h), so it runs on
+        # a second context of libpvw_hip_tuning.so holding its own copy of the public key.
+        try:
+            prev = _ffi.select("tuning")
+            try:
+                pt = (P.PvwParametersBuilder().set_parties(n_total).set_dimension(k).set_l(l).set_moduli(moduli)
+                      .set_device(local_rank).build())
+                P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(pt, SEED_A)).fill_uniform(SEED_B)
+            finally:
+                _ffi.select(prev)
+            sec, nbytes = C.c_double(0.0), C.c_uint64(0)
+            pt._call("pvw_selftest_read_bandwidth", 20, C.byref(sec), C.byref(nbytes))
+            if sec.value > 0:
+                gbps = nbytes.value / sec.value / 1e9
+                out["roofline"]["read_probe"] = {"GBps": gbps, "bytes_per_pass": nbytes.value,
+                                                 "mac_rows_over_probe": achieved / gbps,
+                                                 "note": "same loads as mac_rows (1-KiB tiles, 16 B/lane, nt, 16 in flight per wave), xor instead of the modular MAC; libpvw_hip_tuning.so"}
+            del pt
+        except Exception as e:                 # the tuning build is optional equipment
+            out["roofline"]["read_probe"] = {"error": str(e)[:200]}
     if Dm > 0:
         out["metric"] = ("party-ciphertexts/s for encrypt_all_party_shares (D dealers x n parties, "
                          + ("batches of 16, up to 128 per launch" if gemm_path else "4") + " dealers per pass over B-hat)")
         out["unit"] = "party-ciphertexts/s"
+        if "sustained" in out:
+            out["sustained"]["unit"] = out["unit"]
         out["roofline"]["kernel"] = "gemm_digits_kernel (i8 MFMA)" if gemm_path else "mac_rows_multi_kernel"
         mm = L * l * (n_per * k + rows_a * k) * nv / mac_avg_s if mac_avg_s > 0 else 0.0
         out["roofline"]["modular_macs_per_s"] = mm
@@ -258,6 +317,9 @@ def main():
                                    "note": "pvw_encrypt with pageable host buffers, synchronous, PCIe-inclusive (c1+c2 = "
                                            f"{(k + n_total) * L * l * 8 / 1e6:.1f} MB D2H per call); median of 20 calls",
                                    "bit_exact_vs_device_path": bool(np.array_equal(c2h.view(np.int64), c2.cpu().numpy()))}
+        # the ONLY place bench.py touches oracle/: the checker timed as the CPU baseline
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pvw_model as M
         import pvw_oracle as O
         n_cpu = min(n_per, 4096)
         orc = O.Oracle(moduli, l)
@@ -297,12 +359,11 @@ def bench_keygen(args, world, rank, local_rank, dev):
     import numpy as np
     import torch  # noqa: F401
 
-    import pvw_model as M
     import pvw_rs_amd as P
     from pvw_rs_amd import _ffi
 
     n_per, k, l, L, desc = CONFIGS[args.config or "c3"]
-    moduli = M.bench_moduli(L)
+    moduli = W.bench_moduli(L)
     from pvw_rs_amd import dist as D
     lo, hi, _, _ = D.shard_ranges(n_per * world, k, world, rank)
     params = (P.PvwParametersBuilder().set_parties(n_per * world).set_dimension(k).set_l(l).set_moduli(moduli)
@@ -347,12 +408,11 @@ def bench_decrypt(args, world, rank, local_rank, dev):
     import numpy as np
     import torch
 
-    import pvw_model as M
     import pvw_rs_amd as P
     from pvw_rs_amd import _ffi
 
     D, k, l, L, desc = DECRYPT_CONFIGS[args.config or "c5shard"]
-    moduli = M.bench_moduli(L)
+    moduli = W.bench_moduli(L)
     params = (P.PvwParametersBuilder().set_parties(D * world).set_dimension(k).set_l(l).set_moduli(moduli)
               .set_device(local_rank).build())
     h, lib = params._h, _ffi.lib()

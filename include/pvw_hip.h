@@ -150,6 +150,10 @@ PVW_API int32_t pvw_load_crs_device(pvw_ctx* ctx, const uint64_t* d_a, uint32_t 
 /* PvwCrs::new_deterministic analogue (crs.rs:45-67): uniform NTT-domain polynomials from a
  * 32-byte seed with this library's ChaCha8 streams (PVW_DOM_CRS) -- not fhe-math's bytes. */
 PVW_API int32_t pvw_crs_generate(pvw_ctx* ctx, const uint8_t seed[32]);
+/* PvwCrs::new_from_tag (crs.rs:74-90): the 32-byte seed the reference derives from a string tag -- the 64-bit
+ * std DefaultHasher (SipHash-1-3, zero key) of tag + "CRS", little-endian, repeated four times.  Feed it to
+ * pvw_crs_generate.  (PvwCrs::new, crs.rs:24-39, is pvw_crs_generate with a seed from the host's entropy source.) */
+PVW_API int32_t pvw_crs_seed_from_tag(const char* tag, uint8_t seed_out[32]);
 /* download: a_out host [k][k][L][l] (only rows held by this context are written) */
 PVW_API int32_t pvw_get_crs(pvw_ctx* ctx, uint64_t* a_out, uint32_t repr);
 
@@ -242,9 +246,19 @@ PVW_API int32_t pvw_selftest_decode_fixed(const pvw_ctx* ctx, const uint64_t* no
 /* SELF-TEST: C[32][32] (int32) = A[32][32] * B[32][32] (int8, row-major) with one i8 MFMA fetched
  * through the lane maps the digit-GEMM kernels assume. */
 PVW_API int32_t pvw_selftest_mfma_i8(pvw_ctx* ctx, const int8_t* a, const int8_t* b, int32_t* out);
-/* MEASUREMENT AID (bench.py): seconds per pass of a read-only kernel with the access pattern of the streamed
- * inner products (crs.rs:188-201, encryption.rs:177-200) over the resident public-key section */
-PVW_API int32_t pvw_selftest_read_bandwidth(pvw_ctx* ctx, uint32_t reps, double* seconds_per_pass, uint64_t* bytes_per_pass);
+/* SELF-TEST: key hygiene.  SecretKey is Zeroize + ZeroizeOnDrop in the reference (src/keys/secret_key.rs:20-30);
+ * here every device region that held key material during pvw_keygen / pvw_decrypt_* / pvw_sample_secret_keys
+ * (uploaded coefficients, NTT(sk), key errors, their tiled / digitised copies) is cleared on the call's stream
+ * before the call returns its workspace.  Reports how many 64-bit words of those regions (as declared by the
+ * last such call on each pooled workspace) are not zero, and how many were scanned. */
+PVW_API int32_t pvw_selftest_secret_residue(pvw_ctx* ctx, uint64_t* nonzero_words, uint64_t* scanned_words);
+/* SELF-TEST: SipHash-c-d of msg under (k0, k1) -- the hash behind pvw_crs_seed_from_tag, exposed so that it can be
+ * pinned against the published SipHash-2-4 vector */
+PVW_API int32_t pvw_selftest_siphash(const uint8_t* msg, size_t len, uint64_t k0, uint64_t k1, int32_t c_rounds,
+                                     int32_t d_rounds, uint64_t* out);
+/* 1 for the measurement build libpvw_hip_tuning.so (include/pvw_hip_tuning.h: environment-selected kernel
+ * schedules, timing ablations, bandwidth probe), 0 for the shipped library, which reads no environment variable */
+PVW_API int32_t pvw_build_is_tuning(void);
 
 /* ---- ring primitives (fhe-math call sites) -----------------------
  * change_representation(Ntt / PowerBasis) on `count` polynomials, host buffers, in place */

@@ -1,0 +1,24 @@
+/* pvw_hip_tuning.h -- entry points that exist ONLY in the measurement build libpvw_hip_tuning.so
+ * (hipcc -DPVW_TUNING=1, pvw_rs_amd/build.py).  That build also honours the environment switches listed in
+ * DESIGN.md section 7a (kernel schedule selectors such as PVW_MAC_VARIANT / PVW_DEC_VARIANT, and the timing
+ * ablations PVW_PROLOGUE_DEBUG / PVW_GEMM_DEBUG / PVW_DECODE_TIMING, which produce WRONG results by design).
+ * The shipped libpvw_hip.so exports none of this and reads no environment variable: the reference samples and
+ * computes unconditionally (src/crypto/encryption.rs:135-167), and so must its drop-in.
+ * the tools/ scripts, bench.py's read_probe leg and tests/test_gpu_tuning.py load the tuning build; nothing else does. */
+#ifndef PVW_HIP_TUNING_H
+#define PVW_HIP_TUNING_H
+
+#include "pvw_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MEASUREMENT AID (bench.py): seconds per pass of a read-only kernel with the access pattern of the streamed
+ * inner products (crs.rs:188-201, encryption.rs:177-200) over the resident public-key section */
+PVW_API int32_t pvw_selftest_read_bandwidth(pvw_ctx* ctx, uint32_t reps, double* seconds_per_pass, uint64_t* bytes_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVW_HIP_TUNING_H */

@@ -80,7 +80,10 @@ _SIGNATURES = {
     "pvw_decode_device": [_P, _P, C.c_size_t, _P, _P],
     "pvw_selftest_decode_fixed": [_P, _P, C.c_size_t, _P],
     "pvw_selftest_mfma_i8": [_P, _P, _P, _P],
-    "pvw_selftest_read_bandwidth": [_P, C.c_uint32, _P, _P],
+    "pvw_selftest_secret_residue": [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "pvw_selftest_siphash": [_P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)],
+    "pvw_build_is_tuning": [],
+    "pvw_crs_seed_from_tag": [C.c_char_p, _P],
     "pvw_ntt_forward": [_P, _P, C.c_size_t],
     "pvw_ntt_inverse": [_P, _P, C.c_size_t],
     "pvw_small_to_poly": [_P, _P, C.c_size_t, _P, C.c_uint32],
@@ -94,27 +97,58 @@ _SIGNATURES = {
     "pvw_ctx_synchronize": [_P],
 }
 
-_lib = None
+# include/pvw_hip_tuning.h: exported by the measurement build only
+_TUNING_SIGNATURES = {
+    "pvw_selftest_read_bandwidth": [_P, C.c_uint32, _P, _P],
+}
+
+LIB_TUNING_PATH = os.path.join(HERE, "libpvw_hip_tuning.so")
+_libs = {}
+# which build `lib()` hands out.  "tuning" is for tools/*.sh (PVW_HIP_LIBRARY=tuning in the environment of the
+# PYTHON host -- the shipped .so itself reads no environment variable) and for tests/test_gpu_tuning.py, which
+# switches with `select()`; every PvwParameters remembers the library it was created with.
+_selected = "tuning" if os.environ.get("PVW_HIP_LIBRARY") == "tuning" else "default"
 
 
-def lib() -> C.CDLL:
-    """Load libpvw_hip.so (built by pvw_rs_amd.build / __graft_entry__.build)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def _load(which: str) -> C.CDLL:
+    if which not in _libs:
+        path = LIB_TUNING_PATH if which == "tuning" else LIB_PATH
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: the PVW hot path is HIP-only, run "
+                f"{path} is missing: the PVW hot path is HIP-only, run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` first")
-        L = C.CDLL(LIB_PATH)
-        for name, args in _SIGNATURES.items():
+        L = C.CDLL(path)
+        sigs = dict(_SIGNATURES)
+        if which == "tuning":
+            sigs.update(_TUNING_SIGNATURES)
+        for name, args in sigs.items():
             fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
             fn.argtypes = args
             fn.restype = C.c_int32
-        _lib = L
-    return _lib
+        _libs[which] = L
+    return _libs[which]
 
 
-def last_error() -> str:
+def lib() -> C.CDLL:
+    """The selected HIP library (libpvw_hip.so unless the tuning build was selected)."""
+    return _load(_selected)
+
+
+def tuning_lib() -> C.CDLL:
+    """libpvw_hip_tuning.so (-DPVW_TUNING=1): schedule selectors, timing ablations, bandwidth probe."""
+    return _load("tuning")
+
+
+def select(which: str) -> str:
+    """Choose the build later `lib()` calls return ("default" | "tuning"); returns the previous choice."""
+    global _selected
+    if which not in ("default", "tuning"):
+        raise ValueError(which)
+    prev, _selected = _selected, which
+    return prev
+
+
+def last_error(L: C.CDLL = None) -> str:
     buf = C.create_string_buffer(512)
-    lib().pvw_last_error(buf, 512)
+    (L or lib()).pvw_last_error(buf, 512)
     return buf.value.decode("utf-8", "replace")

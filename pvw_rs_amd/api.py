@@ -31,9 +31,9 @@ class PvwError(Exception):
         super().__init__(f"{self.variant}: {message}")
 
 
-def _check(rc: int) -> None:
+def _check(rc: int, lib=None) -> None:
     if rc != _ffi.PVW_OK:
-        raise PvwError(rc, _ffi.last_error())
+        raise PvwError(rc, _ffi.last_error(lib))
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -131,7 +131,8 @@ class PvwParameters:
         p.party_lo, p.party_hi, p.c1_lo, p.c1_hi = shard
         h = C.c_void_p()
         self._h = None
-        _check(_ffi.lib().pvw_ctx_create(C.byref(p), C.byref(h)))
+        self._lib = _ffi.lib()              # the build selected now serves this context for its whole life
+        _check(self._lib.pvw_ctx_create(C.byref(p), C.byref(h)), self._lib)
         self._h = h
         self.t = (self.n - 1) // 2                                        # :169
         self.party_lo, self.party_hi = (shard[0], shard[1]) if (shard[0] or shard[1]) else (0, self.n)
@@ -140,7 +141,7 @@ class PvwParameters:
     def __del__(self):
         if getattr(self, "_h", None):
             try:
-                _ffi.lib().pvw_ctx_destroy(self._h)
+                self._lib.pvw_ctx_destroy(self._h)
             except Exception:
                 pass
             self._h = None
@@ -162,36 +163,42 @@ class PvwParameters:
     def moduli(self) -> List[int]:
         return [int(q) for q in self._moduli]
 
-    def _big(self, fn) -> int:
+    def _call(self, name: str, *args) -> None:
+        """one C-ABI call on this context, through the library the context was created with"""
+        rc = getattr(self._lib, name)(self._h, *args)
+        if rc != _ffi.PVW_OK:
+            raise PvwError(rc, _ffi.last_error(self._lib))
+
+    def _big(self, name) -> int:
         n = C.c_size_t()
-        _check(fn(self._h, None, 0, C.byref(n)))
+        self._call(name, None, 0, C.byref(n))
         w = np.zeros(max(n.value, 1), dtype=np.uint64)
-        _check(fn(self._h, _ptr(w), len(w), C.byref(n)))
+        self._call(name, _ptr(w), len(w), C.byref(n))
         return sum(int(w[i]) << (64 * i) for i in range(n.value))
 
     def delta(self) -> int:
-        return self._big(_ffi.lib().pvw_ctx_delta)
+        return self._big("pvw_ctx_delta")
 
     def delta_power_l_minus_1(self) -> int:
-        return self._big(_ffi.lib().pvw_ctx_delta_power_l_minus_1)
+        return self._big("pvw_ctx_delta_power_l_minus_1")
 
     def q_total(self) -> int:
-        return self._big(_ffi.lib().pvw_ctx_q_total)
+        return self._big("pvw_ctx_q_total")
 
     def roots(self) -> List[int]:
         w = np.zeros(self.L, dtype=np.uint64)
-        _check(_ffi.lib().pvw_ctx_get_roots(self._h, _ptr(w)))
+        self._call("pvw_ctx_get_roots", _ptr(w))
         return [int(x) for x in w]
 
     def set_roots(self, psi: Sequence[int]) -> None:
         w = _u64(list(psi))
         if len(w) != self.L:
             raise PvwError(15, f"expected {self.L}, got {len(w)}")
-        _check(_ffi.lib().pvw_ctx_set_roots(self._h, _ptr(w)))
+        self._call("pvw_ctx_set_roots", _ptr(w))
 
     def gadget_polynomial(self, repr: int = REPR_POWER) -> np.ndarray:   # :288-308
         out = np.zeros((self.L, self.l), dtype=np.uint64)
-        _check(_ffi.lib().pvw_ctx_gadget(self._h, _ptr(out), repr))
+        self._call("pvw_ctx_gadget", _ptr(out), repr)
         return out
 
     def gadget_vector(self) -> List[int]:                                 # :311-324
@@ -200,12 +207,12 @@ class PvwParameters:
 
     def encode_scalar(self, scalar: int, repr: int = REPR_POWER) -> np.ndarray:   # :346-367
         out = np.zeros((self.L, self.l), dtype=np.uint64)
-        _check(_ffi.lib().pvw_encode_scalar(self._h, C.c_int64(scalar), _ptr(out), repr))
+        self._call("pvw_encode_scalar", C.c_int64(scalar), _ptr(out), repr)
         return out
 
     def verify_correctness_condition(self) -> bool:                       # :510-551
         ok = C.c_int32()
-        _check(_ffi.lib().pvw_ctx_verify_correctness_condition(self._h, C.byref(ok)))
+        self._call("pvw_ctx_verify_correctness_condition", C.byref(ok))
         return bool(ok.value)
 
     @staticmethod
@@ -238,55 +245,55 @@ class PvwParameters:
         a = _i64(coeffs)
         count = a.size // self.l
         out = np.zeros(a.shape[:-1] + (self.L, self.l), dtype=np.uint64)
-        _check(_ffi.lib().pvw_small_to_poly(self._h, _ptr(a), count, _ptr(out), repr))
+        self._call("pvw_small_to_poly", _ptr(a), count, _ptr(out), repr)
         return out
 
     def ntt_forward(self, polys) -> np.ndarray:
         a = _u64(polys).copy()
-        _check(_ffi.lib().pvw_ntt_forward(self._h, _ptr(a), a.size // (self.L * self.l)))
+        self._call("pvw_ntt_forward", _ptr(a), a.size // (self.L * self.l))
         return a
 
     def ntt_inverse(self, polys) -> np.ndarray:
         a = _u64(polys).copy()
-        _check(_ffi.lib().pvw_ntt_inverse(self._h, _ptr(a), a.size // (self.L * self.l)))
+        self._call("pvw_ntt_inverse", _ptr(a), a.size // (self.L * self.l))
         return a
 
     # -- samplers (src/sampling) --------------------------------------------------------
     def sample_vec_cbd(self, seed: bytes, domain: int, index0: int, count: int, variance=None) -> np.ndarray:
         out = np.zeros((count, self.l), dtype=np.int64)
         v = self.secret_variance if variance is None else variance
-        _check(_ffi.lib().pvw_sample_cbd(self._h, _ptr(_seed(seed)), domain, index0, count, v, _ptr(out)))
+        self._call("pvw_sample_cbd", _ptr(_seed(seed)), domain, index0, count, v, _ptr(out))
         return out
 
     def sample_uniform_coefficients(self, seed: bytes, domain: int, index0: int, count: int, bound: int) -> np.ndarray:
         out = np.zeros((count, self.l), dtype=np.int64)
-        _check(_ffi.lib().pvw_sample_uniform(self._h, _ptr(_seed(seed)), domain, index0, count, bound, _ptr(out)))
+        self._call("pvw_sample_uniform", _ptr(_seed(seed)), domain, index0, count, bound, _ptr(out))
         return out
 
     def sample_discrete_gaussian_vec(self, seed: bytes, bound: int, n: int, index0: int = 0) -> np.ndarray:
         out = np.zeros(n, dtype=np.int64)
-        _check(_ffi.lib().pvw_sample_gaussian(self._h, _ptr(_seed(seed)), index0, n, bound, _ptr(out)))
+        self._call("pvw_sample_gaussian", _ptr(_seed(seed)), index0, n, bound, _ptr(out))
         return out
 
     # -- measurement ----------------------------------------------------------------------
     def set_profiling(self, on: bool) -> None:
-        _check(_ffi.lib().pvw_ctx_set_profiling(self._h, int(on)))
+        self._call("pvw_ctx_set_profiling", int(on))
 
     def reset_profiling(self) -> None:
-        _check(_ffi.lib().pvw_ctx_reset_profiling(self._h))
+        self._call("pvw_ctx_reset_profiling")
 
     def kernel_time(self, name: str) -> Tuple[float, int]:
         ms, cnt = C.c_double(), C.c_uint64()
-        _check(_ffi.lib().pvw_ctx_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(cnt)))
+        self._call("pvw_ctx_kernel_time", name.encode(), C.byref(ms), C.byref(cnt))
         return ms.value, cnt.value
 
     def resident_bytes(self) -> Tuple[int, int]:
         a, b = C.c_uint64(), C.c_uint64()
-        _check(_ffi.lib().pvw_ctx_resident_bytes(self._h, C.byref(a), C.byref(b)))
+        self._call("pvw_ctx_resident_bytes", C.byref(a), C.byref(b))
         return a.value, b.value
 
     def synchronize(self) -> None:
-        _check(_ffi.lib().pvw_ctx_synchronize(self._h))
+        self._call("pvw_ctx_synchronize")
 
 
 # ------------------------------------------------------------------------------------
@@ -299,8 +306,31 @@ class PvwCrs:
         self.params = params
 
     @staticmethod
+    def new(params: PvwParameters, rng=None) -> "PvwCrs":                    # crs.rs:24-39
+        """Fresh random CRS: `rng` is anything with `.bytes(32)` / `.randbytes(32)` (default: the OS entropy
+        source, the reference takes a CryptoRng); the polynomials come from this library's seeded streams."""
+        if rng is None:
+            import os
+            seed = os.urandom(32)
+        else:
+            seed = bytes(rng.bytes(32) if hasattr(rng, "bytes") else rng.randbytes(32))
+        return PvwCrs.new_deterministic(params, seed)
+
+    @staticmethod
+    def seed_from_tag(tag: str) -> bytes:
+        """The 32-byte seed PvwCrs::new_from_tag derives (crs.rs:75-87): DefaultHasher(tag + "CRS") as 8
+        little-endian bytes, repeated four times."""
+        out = np.zeros(32, dtype=np.uint8)
+        _check(_ffi.lib().pvw_crs_seed_from_tag(tag.encode("utf-8"), _ptr(out)))
+        return out.tobytes()
+
+    @staticmethod
+    def new_from_tag(params: PvwParameters, tag: str) -> "PvwCrs":           # crs.rs:74-90
+        return PvwCrs.new_deterministic(params, PvwCrs.seed_from_tag(tag))
+
+    @staticmethod
     def new_deterministic(params: PvwParameters, seed: bytes) -> "PvwCrs":   # crs.rs:45-67
-        _check(_ffi.lib().pvw_crs_generate(params._h, _ptr(_seed(seed))))
+        params._call("pvw_crs_generate", _ptr(_seed(seed)))
         return PvwCrs(params)
 
     @staticmethod
@@ -309,7 +339,7 @@ class PvwCrs:
         want = (params.k, params.k, params.L, params.l)
         if a.shape != want:
             raise PvwError(15, f"expected {want}, got {a.shape}")
-        _check(_ffi.lib().pvw_load_crs(params._h, _ptr(a), repr))
+        params._call("pvw_load_crs", _ptr(a), repr)
         return PvwCrs(params)
 
     def dimensions(self) -> Tuple[int, int]:
@@ -318,7 +348,7 @@ class PvwCrs:
     def matrix(self, repr: int = REPR_POWER) -> np.ndarray:
         p = self.params
         out = np.zeros((p.k, p.k, p.L, p.l), dtype=np.uint64)
-        _check(_ffi.lib().pvw_get_crs(p._h, _ptr(out), repr))
+        p._call("pvw_get_crs", _ptr(out), repr)
         return out
 
     def get(self, i: int, j: int, repr: int = REPR_POWER) -> Optional[np.ndarray]:   # crs.rs:93
@@ -338,13 +368,15 @@ class SecretKey:
 
     def __init__(self, params: PvwParameters, secret_coeffs: np.ndarray):
         self.params = params
-        self.secret_coeffs = _i64(secret_coeffs)
+        self.secret_coeffs = np.array(secret_coeffs, dtype=np.int64, order="C", copy=True)   # owned: zeroized on drop
 
     @staticmethod
     def random(params: PvwParameters, seed: bytes, party_index: int = 0) -> "SecretKey":   # :45-63
         out = np.zeros((params.k, params.l), dtype=np.int64)
-        _check(_ffi.lib().pvw_sample_secret_keys(params._h, _ptr(_seed(seed)), party_index, 1, _ptr(out)))
-        return SecretKey(params, out)
+        params._call("pvw_sample_secret_keys", _ptr(_seed(seed)), party_index, 1, _ptr(out))
+        key = SecretKey(params, out)
+        out.fill(0)
+        return key
 
     @staticmethod
     def from_coefficients(params: PvwParameters, coeffs) -> "SecretKey":
@@ -355,6 +387,18 @@ class SecretKey:
 
     def coefficients(self) -> np.ndarray:
         return self.secret_coeffs
+
+    def zeroize(self) -> None:
+        """Zeroize / ZeroizeOnDrop (secret_key.rs:20-30): overwrite the coefficients in place (the device side
+        clears its own copies before every call returns, see pvw_selftest_secret_residue)."""
+        if getattr(self, "secret_coeffs", None) is not None and self.secret_coeffs.flags.writeable:
+            self.secret_coeffs.fill(0)
+
+    def __del__(self):
+        try:
+            self.zeroize()
+        except Exception:
+            pass
 
     def get_polynomial(self, index: int) -> np.ndarray:                   # :98-112 (NTT form)
         if not 0 <= index < len(self.secret_coeffs):
@@ -396,12 +440,12 @@ class GlobalPublicKey:
             raise PvwError(1, f"Party index {index} exceeds maximum {p.n - 1}")
         if b.shape != (p.k, p.L, p.l):
             raise PvwError(1, f"Public key dimension {b.shape[0]} doesn't match parameter k={p.k}")
-        _check(_ffi.lib().pvw_load_pk(p._h, index, index + 1, _ptr(b), repr))
+        p._call("pvw_load_pk", index, index + 1, _ptr(b), repr)
 
     def load_rows(self, party_lo: int, rows: np.ndarray, repr: int = REPR_POWER) -> None:
         p = self.params
         b = _u64(rows)
-        _check(_ffi.lib().pvw_load_pk(p._h, party_lo, party_lo + b.shape[0], _ptr(b), repr))
+        p._call("pvw_load_pk", party_lo, party_lo + b.shape[0], _ptr(b), repr)
 
     def generate_and_add_party(self, party: Party, seed: bytes) -> None:   # :256-263
         self._keygen(party.index, party.index + 1, party.secret_key.secret_coeffs[None], None, seed)
@@ -409,8 +453,17 @@ class GlobalPublicKey:
     def generate_all_party_keys(self, parties: Sequence[Party], seed: bytes) -> None:   # :376-401
         if len(parties) > self.params.n:
             raise PvwError(1, f"Too many parties: {len(parties)} > {self.params.n}")
-        for party in parties:
-            self.generate_and_add_party(party, seed)
+        # the reference generates the keys in parallel and adds them in order (:387-399); here every run of
+        # consecutive party indices is ONE batched device call (the matrix-core path from 8 parties up)
+        i = 0
+        while i < len(parties):
+            j = i + 1
+            while j < len(parties) and parties[j].index == parties[j - 1].index + 1:
+                j += 1
+            sk = np.stack([pt.secret_key.secret_coeffs for pt in parties[i:j]])
+            self._keygen(parties[i].index, parties[i].index + (j - i), sk, None, seed)
+            sk.fill(0)
+            i = j
 
     def generate_with_errors(self, party_lo: int, sk: np.ndarray, ek: np.ndarray) -> None:
         """b_i = s_i*A + e_i with explicit key errors (public_key.rs:111-147)."""
@@ -421,16 +474,16 @@ class GlobalPublicKey:
         sk = _i64(sk)
         ekp = None if ek is None else _i64(ek)
         sd = None if seed is None else _seed(seed)
-        _check(_ffi.lib().pvw_keygen(p._h, lo, hi, _ptr(sk), _ptr(ekp), _ptr(sd)))
+        p._call("pvw_keygen", lo, hi, _ptr(sk), _ptr(ekp), _ptr(sd))
 
     def fill_uniform(self, seed: bytes) -> None:
-        _check(_ffi.lib().pvw_pk_fill_uniform(self.params._h, _ptr(_seed(seed))))
+        self.params._call("pvw_pk_fill_uniform", _ptr(_seed(seed)))
 
     def matrix(self, party_lo: int = 0, party_hi: Optional[int] = None, repr: int = REPR_POWER) -> np.ndarray:
         p = self.params
         hi = p.n if party_hi is None else party_hi
         out = np.zeros((hi - party_lo, p.k, p.L, p.l), dtype=np.uint64)
-        _check(_ffi.lib().pvw_get_pk(p._h, party_lo, hi, _ptr(out), repr))
+        p._call("pvw_get_pk", party_lo, hi, _ptr(out), repr)
         return out
 
     def get_polynomial(self, i: int, j: int, repr: int = REPR_POWER) -> Optional[np.ndarray]:   # :334-336
@@ -444,12 +497,12 @@ class GlobalPublicKey:
 
     def num_public_keys(self) -> int:                                      # :344
         out = C.c_uint32()
-        _check(_ffi.lib().pvw_num_public_keys(self.params._h, C.byref(out)))
+        self.params._call("pvw_num_public_keys", C.byref(out))
         return out.value
 
     def is_full(self) -> bool:                                             # :349
         out = C.c_int32()
-        _check(_ffi.lib().pvw_is_full(self.params._h, C.byref(out)))
+        self.params._call("pvw_is_full", C.byref(out))
         return bool(out.value)
 
 
@@ -514,7 +567,7 @@ def encrypt(scalars: Sequence[int], global_pk: GlobalPublicKey, seed: Optional[b
     rnd, keep = _randomness(p, seed, r, e1, e2)
     c1 = np.zeros((p.k, p.L, p.l), dtype=np.uint64)
     c2 = np.zeros((p.n, p.L, p.l), dtype=np.uint64)
-    _check(_ffi.lib().pvw_encrypt(p._h, _ptr(sc), len(sc), C.byref(rnd), _ptr(c1), _ptr(c2), repr))
+    p._call("pvw_encrypt", _ptr(sc), len(sc), C.byref(rnd), _ptr(c1), _ptr(c2), repr)
     del keep
     ct = PvwCiphertext(c1, c2, p, repr)
     ct.validate()                                                          # :204-211
@@ -569,7 +622,7 @@ def encrypt_many(all_scalars: Sequence[Sequence[int]], global_pk: GlobalPublicKe
     sd = np.concatenate([_seed(s) for s in seeds]) if D else np.zeros(0, dtype=np.uint8)
     c1 = np.zeros((D, p.k, p.L, p.l), dtype=np.uint64)
     c2 = np.zeros((D, p.n, p.L, p.l), dtype=np.uint64)
-    _check(_ffi.lib().pvw_encrypt_multi(p._h, _ptr(sc), D, sc.shape[1] if D else 0, _ptr(sd), _ptr(c1), _ptr(c2), repr))
+    p._call("pvw_encrypt_multi", _ptr(sc), D, sc.shape[1] if D else 0, _ptr(sd), _ptr(c1), _ptr(c2), repr)
     return [PvwCiphertext(c1[d], c2[d], p, repr) for d in range(D)]
 
 
@@ -603,8 +656,8 @@ def _decrypt_batch(p, cts, secret_key, party_index, return_noisy=False):
     sk = _i64(secret_key.secret_coeffs)
     out = np.zeros(len(cts), dtype=np.uint64)
     noisy = np.zeros((len(cts), p.L, p.l), dtype=np.uint64) if return_noisy else None
-    _check(_ffi.lib().pvw_decrypt_batch(p._h, _ptr(sk), _ptr(c1s), _ptr(c2col), len(cts), repr,
-                                        _ptr(out), _ptr(noisy)))
+    p._call("pvw_decrypt_batch", _ptr(sk), _ptr(c1s), _ptr(c2col), len(cts), repr,
+                                        _ptr(out), _ptr(noisy))
     vals = [int(v) for v in out]
     return (vals, noisy) if return_noisy else vals
 
@@ -614,11 +667,18 @@ def decrypt_party_value(ciphertext: PvwCiphertext, secret_key: SecretKey, party_
     return _decrypt_batch(ciphertext.params, [ciphertext], secret_key, party_index)[0]
 
 
+def _secret_residue(params: PvwParameters) -> Tuple[int, int]:
+    """(non-zero words, scanned words) of the device regions the last key-bearing calls declared secret."""
+    nz, sc = C.c_uint64(), C.c_uint64()
+    params._call("pvw_selftest_secret_residue", C.byref(nz), C.byref(sc))
+    return nz.value, sc.value
+
+
 def _selftest_decode_fixed(params: PvwParameters, noisy: np.ndarray) -> List[int]:
     """Host run of the fixed-width decode the GPU executes (self-test hook, see pvw_hip.h)."""
     a = _u64(noisy).reshape(-1, params.L, params.l)
     out = np.zeros(len(a), dtype=np.uint64)
-    _check(_ffi.lib().pvw_selftest_decode_fixed(params._h, _ptr(a), len(a), _ptr(out)))
+    params._call("pvw_selftest_decode_fixed", _ptr(a), len(a), _ptr(out))
     return [int(v) for v in out]
 
 
@@ -626,7 +686,7 @@ def decode_scalar_pvw(params: PvwParameters, noisy: np.ndarray) -> List[int]:
     """decode_scalar_pvw_rns (decryption.rs:10-58) on power-basis noisy polynomials [D][L][l], on the device."""
     a = _u64(noisy).reshape(-1, params.L, params.l)
     out = np.zeros(len(a), dtype=np.uint64)
-    _check(_ffi.lib().pvw_decode(params._h, _ptr(a), len(a), _ptr(out)))
+    params._call("pvw_decode", _ptr(a), len(a), _ptr(out))
     return [int(v) for v in out]
 
 
@@ -634,5 +694,5 @@ def decode_scalar_pvw_host(params: PvwParameters, noisy: np.ndarray) -> List[int
     """The same decode with host big integers (no GPU): cross-check of the device algorithm."""
     a = _u64(noisy).reshape(-1, params.L, params.l)
     out = np.zeros(len(a), dtype=np.uint64)
-    _check(_ffi.lib().pvw_decode_host(params._h, _ptr(a), len(a), _ptr(out)))
+    params._call("pvw_decode_host", _ptr(a), len(a), _ptr(out))
     return [int(v) for v in out]

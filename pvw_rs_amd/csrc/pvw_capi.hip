@@ -24,6 +24,9 @@
 #include "pvw_chacha.h"
 #include "pvw_decode.h"
 #include "pvw_kernels.h"
+#if PVW_TUNING
+#include "../../include/pvw_hip_tuning.h"
+#endif
 
 using namespace pvw;
 
@@ -112,7 +115,8 @@ struct ProfRec {
 struct Workspace {
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  u64* rhat = nullptr;       // [L][k][l]
+  u64* rhat = nullptr;       // [L][k][l]  (x4: up to four r-hat / s-hat vectors)
+  size_t rhat_bytes = 0;
   u64* scalars = nullptr;    // [n]
   u64* c1 = nullptr;         // [rowsA][L][l]
   u64* c2 = nullptr;         // [rowsB][L][l]
@@ -128,7 +132,27 @@ struct Workspace {
   // helper stream + events for pvw_decrypt_batch_device (decode of chunk i under the MAC of chunk i+1)
   hipStream_t aux = nullptr;
   std::vector<hipEvent_t> events;
+  // device regions that hold secret-key material during the current call (sk coefficients, NTT(sk), key errors,
+  // their MFMA-tiled / digitised copies): cleared on the call's stream before the workspace goes back to the pool
+  // (the reference's SecretKey is Zeroize + ZeroizeOnDrop, src/keys/secret_key.rs:20-30).  `wiped` remembers what
+  // the last call cleared, for pvw_selftest_secret_residue.
+  struct Span { void* p; size_t bytes; };
+  std::vector<Span> secrets, wiped;
 };
+static void ws_mark_secret(Workspace* w, void* p, size_t bytes) {
+  if (p && bytes) w->secrets.push_back(Workspace::Span{p, bytes});
+}
+// enqueue the wipes on `s` (call after the last kernel that reads the regions has been enqueued on `s`)
+static hipError_t ws_wipe_secrets(Workspace* w, hipStream_t s) {
+  hipError_t rc = hipSuccess;
+  for (const Workspace::Span& sp : w->secrets) {
+    hipError_t e = hipMemsetAsync(sp.p, 0, sp.bytes, s);
+    if (e != hipSuccess) rc = e;
+  }
+  w->wiped = w->secrets;
+  w->secrets.clear();
+  return rc;
+}
 
 struct pvw_ctx {
   u32 n, k, l, L;
@@ -371,6 +395,7 @@ static int32_t ensure_device(pvw_ctx* c) {
     return fail(PVW_ERR_INTERNAL, std::string("kernels are built for gfx950 only, device is ") +
                                       prop.gcnArchName);
   PVW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PVW_HIP(init_kernel_attributes());          // per device: dynamic-LDS limits of the decode kernels
   PVW_TRY(upload_tables(c));
   c->dev_ready = true;
   c->roots_locked = true;
@@ -380,6 +405,7 @@ static int32_t ensure_device(pvw_ctx* c) {
 static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
   const size_t k = c->k, P = c->poly();
   PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
+  w->rhat_bytes = 4 * k * P * 8;
   return PVW_OK;
 }
 static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
@@ -391,7 +417,10 @@ static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
 }
 static int32_t ws_scratch(Workspace* w, size_t bytes) {
   if (w->scratch_bytes >= bytes) return PVW_OK;
-  if (w->scratch) hipFree(w->scratch);
+  // callers grow the scratch before they enqueue anything that uses it; whatever an earlier call left there is
+  // cleared before the block goes back to the allocator
+  if (w->scratch) { hipMemset(w->scratch, 0, w->scratch_bytes); hipFree(w->scratch); }
+  w->wiped.clear();
   w->scratch = nullptr;
   w->scratch_bytes = 0;
   PVW_HIP(hipMalloc(&w->scratch, bytes));
@@ -400,6 +429,9 @@ static int32_t ws_scratch(Workspace* w, size_t bytes) {
 }
 static void ws_free(Workspace* w) {
   if (!w) return;
+  // r-hat / s-hat vectors and the staging block may hold key material of the last call
+  if (w->rhat && w->rhat_bytes) hipMemset(w->rhat, 0, w->rhat_bytes);
+  if (w->scratch) hipMemset(w->scratch, 0, w->scratch_bytes);
   hipFree(w->rhat);
   hipFree(w->scalars);
   hipFree(w->c1);
@@ -742,10 +774,9 @@ static int32_t load_rows_host(pvw_ctx* c, u64* M, u32 shard_lo, u32 shard_hi, u3
   return rc;
 }
 // dealers per gemm_digits launch: PVW_GEMM_VB batches of 16 (they share one pass over the matrix through L2)
-static u32 gemm_vb() {
-  static u32 v = [] {
-    const char* e = getenv("PVW_GEMM_VB");
-    int x = e ? atoi(e) : 8;
+static u32 gemm_vb() {   // tuning build: PVW_GEMM_VB
+  static const u32 v = [] {
+    const long x = PVW_ENV_INT("PVW_GEMM_VB", 8);
     return (u32)(x < 1 ? 1 : (x > 8 ? 8 : x));
   }();
   return v;
@@ -817,6 +848,85 @@ int32_t pvw_crs_generate(pvw_ctx* c, const uint8_t seed[32]) {
   c->crs_loaded = true;
   return PVW_OK;
 }
+// PvwCrs::new_from_tag (crs.rs:74-90): seed = the 8 little-endian bytes of DefaultHasher(tag + "CRS") repeated
+// four times.  std's DefaultHasher is SipHash-1-3 with a zero key; `str::hash` feeds the bytes followed by 0xFF.
+static u64 siphash(const uint8_t* m, size_t len, u64 k0, u64 k1, int c_rounds, int d_rounds) {
+  u64 v0 = k0 ^ 0x736f6d6570736575ULL, v1 = k1 ^ 0x646f72616e646f6dULL, v2 = k0 ^ 0x6c7967656e657261ULL,
+      v3 = k1 ^ 0x7465646279746573ULL;
+  auto rotl = [](u64 x, int b) { return (x << b) | (x >> (64 - b)); };
+  auto round = [&]() {
+    v0 += v1; v1 = rotl(v1, 13); v1 ^= v0; v0 = rotl(v0, 32);
+    v2 += v3; v3 = rotl(v3, 16); v3 ^= v2;
+    v0 += v3; v3 = rotl(v3, 21); v3 ^= v0;
+    v2 += v1; v1 = rotl(v1, 17); v1 ^= v2; v2 = rotl(v2, 32);
+  };
+  size_t i = 0;
+  for (; i + 8 <= len; i += 8) {
+    u64 w = 0;
+    for (int b = 0; b < 8; ++b) w |= (u64)m[i + b] << (8 * b);
+    v3 ^= w;
+    for (int r = 0; r < c_rounds; ++r) round();
+    v0 ^= w;
+  }
+  u64 w = (u64)(len & 0xff) << 56;
+  for (int b = 0; i + b < len; ++b) w |= (u64)m[i + b] << (8 * b);
+  v3 ^= w;
+  for (int r = 0; r < c_rounds; ++r) round();
+  v0 ^= w;
+  v2 ^= 0xff;
+  for (int r = 0; r < d_rounds; ++r) round();
+  return v0 ^ v1 ^ v2 ^ v3;
+}
+int32_t pvw_selftest_siphash(const uint8_t* msg, size_t len, uint64_t k0, uint64_t k1, int32_t c_rounds, int32_t d_rounds,
+                             uint64_t* out) {
+  if ((!msg && len) || !out || c_rounds < 1 || d_rounds < 1) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  *out = siphash(msg, len, k0, k1, c_rounds, d_rounds);
+  return PVW_OK;
+}
+int32_t pvw_crs_seed_from_tag(const char* tag, uint8_t seed_out[32]) {
+  if (!tag || !seed_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  std::string m = std::string(tag) + "CRS";
+  m.push_back((char)0xFF);                                   // the terminator `impl Hash for str` writes
+  const u64 h = siphash((const uint8_t*)m.data(), m.size(), 0, 0, 1, 3);
+  for (int i = 0; i < 32; ++i) seed_out[i] = (uint8_t)(h >> (8 * (i % 8)));
+  return PVW_OK;
+}
+
+int32_t pvw_build_is_tuning(void) { return PVW_TUNING; }
+
+// SELF-TEST: 64-bit words that are not zero in the regions the last key-bearing call on each pooled workspace
+// declared secret (and cleared), plus every workspace's r-hat / s-hat block.  0 after pvw_keygen / pvw_decrypt_*.
+int32_t pvw_selftest_secret_residue(pvw_ctx* c, uint64_t* nonzero_words, uint64_t* scanned_words) {
+  if (!c || !nonzero_words || !scanned_words) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  *nonzero_words = *scanned_words = 0;
+  if (!c->dev_ready) return PVW_OK;
+  PVW_HIP(hipSetDevice(c->device));
+  PVW_HIP(hipDeviceSynchronize());
+  std::vector<Workspace*> all;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    all = c->pool;
+    for (auto& kv : c->async_ws) all.push_back(kv.second);
+  }
+  std::vector<u64> host;
+  for (Workspace* w : all) {
+    std::vector<Workspace::Span> spans = w->wiped;
+    if (w->rhat) spans.push_back(Workspace::Span{w->rhat, w->rhat_bytes});
+    for (const Workspace::Span& sp : spans) {
+      const size_t step = (size_t)64 << 20;
+      for (size_t off = 0; off < sp.bytes; off += step) {
+        const size_t nb = (sp.bytes - off) < step ? (sp.bytes - off) : step;
+        host.resize((nb + 7) / 8);
+        host.back() = 0;
+        PVW_HIP(hipMemcpy(host.data(), (const char*)sp.p + off, nb, hipMemcpyDeviceToHost));
+        for (u64 v : host) *nonzero_words += v != 0;
+        *scanned_words += host.size();
+      }
+    }
+  }
+  return PVW_OK;
+}
+
 static int32_t get_rows(pvw_ctx* c, const u64* M, u32 shard_lo, u32 shard_hi, u32 lo, u32 hi,
                         uint64_t* dst, uint32_t repr) {
   const u32 a = lo > shard_lo ? lo : shard_lo, b = hi < shard_hi ? hi : shard_hi;
@@ -940,9 +1050,13 @@ int32_t pvw_sample_cbd(pvw_ctx* c, const uint8_t seed[32], uint32_t domain, uint
     if (launch_sample((i64*)w->scratch, make_key(seed), c->l, j, z, z, w->stream) != hipSuccess)
       rc = fail(PVW_ERR_INTERNAL, "sample launch failed");
   }
-  if (rc == PVW_OK && (hipMemcpyAsync(out, w->scratch, count * c->l * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
-                       hipStreamSynchronize(w->stream) != hipSuccess))
+  if (rc == PVW_OK && hipMemcpyAsync(out, w->scratch, count * c->l * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess)
     rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  if (rc == PVW_OK && domain == PVW_DOM_SK) {            // SecretKey::random: the staged coefficients are key material
+    ws_mark_secret(w, w->scratch, count * c->l * 8);
+    if (ws_wipe_secrets(w, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "wipe failed");
+  }
+  if (hipStreamSynchronize(w->stream) != hipSuccess && rc == PVW_OK) rc = fail(PVW_ERR_INTERNAL, "D2H failed");
   ws_release(c, w);
   return rc;
 }
@@ -1215,7 +1329,7 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
                                      size_t D, u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
   const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
   const size_t P = c->poly();
-  const int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 3; }();   // read per call (tests switch it); measured at config 3: 2 dealers 0.23 ms on the VALU vs 0.25 here, 4 dealers 0.43 vs 0.26, 6 dealers 0.67 vs 0.31
+  const int gemm_min = (int)PVW_ENV_INT("PVW_GEMM_MIN_DEALERS", 3);   // tuning build: read per call (tests switch it); measured at config 3: 2 dealers 0.23 ms on the VALU vs 0.25 here, 4 dealers 0.43 vs 0.26, 6 dealers 0.67 vs 0.31
   const bool use_gemm = gemm_min > 0 && D >= (size_t)gemm_min;
   if (use_gemm) {
     PVW_TRY(ws_gemm_buffers(c, w));
@@ -1408,7 +1522,8 @@ int32_t pvw_decode_host(const pvw_ctx* c, const uint64_t* noisy, size_t count, u
   return PVW_OK;
 }
 
-// MEASUREMENT AID: seconds per pass of a read-only kernel with mac_rows' access pattern over the resident public
+#if PVW_TUNING
+// MEASUREMENT AID (tuning build only, include/pvw_hip_tuning.h): seconds per pass of a read-only kernel with mac_rows' access pattern over the resident public
 // key section (B-hat, tiled): what the memory system delivers to this pattern, next to what mac_rows achieves
 int32_t pvw_selftest_read_bandwidth(pvw_ctx* c, uint32_t reps, double* seconds_per_pass, uint64_t* bytes_per_pass) {
   if (!c || !seconds_per_pass || !bytes_per_pass || reps == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
@@ -1437,6 +1552,7 @@ int32_t pvw_selftest_read_bandwidth(pvw_ctx* c, uint32_t reps, double* seconds_p
   ws_release(c, w);
   return rc;
 }
+#endif  // PVW_TUNING
 
 // SELF-TEST: one i8 MFMA through the operand maps the digit-GEMM kernels assume (exact integer data)
 int32_t pvw_selftest_mfma_i8(pvw_ctx* c, const int8_t* a, const int8_t* b, int32_t* out) {
@@ -1528,6 +1644,12 @@ static int32_t decrypt_enqueue(pvw_ctx* c, Workspace* w, const i64* d_sk, u64* d
   }
   return PVW_OK;
 }
+// NTT(sk) sits in w->rhat while a decrypt runs: cleared on the call's stream behind the last kernel that read it
+static int32_t wipe_shat(pvw_ctx* c, Workspace* w, hipStream_t s) {
+  ws_mark_secret(w, w->rhat, (size_t)c->k * c->poly() * 8);
+  PVW_HIP(ws_wipe_secrets(w, s));
+  return PVW_OK;
+}
 
 int32_t pvw_decrypt_noisy_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t* d_c1s, const uint64_t* d_c2col,
                                  size_t D, uint32_t in_repr, uint64_t* d_noisy, void* stream) {
@@ -1538,7 +1660,9 @@ int32_t pvw_decrypt_noisy_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   Workspace* w;
   PVW_TRY(ws_for_stream(c, s, &w));
-  return decrypt_enqueue(c, w, d_sk, const_cast<u64*>(d_c1s), const_cast<u64*>(d_c2col), D, in_repr, d_noisy, s, false);
+  int32_t rc = decrypt_enqueue(c, w, d_sk, const_cast<u64*>(d_c1s), const_cast<u64*>(d_c2col), D, in_repr, d_noisy, s, false);
+  int32_t rw = wipe_shat(c, w, s);
+  return rc != PVW_OK ? rc : rw;
 }
 
 // decrypt_party_shares with device pointers end to end: <sk, c1> - c2, INTT and gadget decode for D dealer
@@ -1560,7 +1684,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
   // chunks of about 2 GiB of ciphertext (measured: at config 5 in full, 18 GB, overlapping the decode is -7 %;
   // with 0.3 GB chunks the cross-stream events cost more than the decode they hide, +29 %): below 3 GiB in all,
   // one pass on the caller's stream.  PVW_DECRYPT_CHUNK=<dealers> overrides.
-  static long chunk_env = [] { const char* e = getenv("PVW_DECRYPT_CHUNK"); return e ? atol(e) : 0L; }();
+  static const long chunk_env = PVW_ENV_INT("PVW_DECRYPT_CHUNK", 0);   // tuning build only
   const double total_gib = (double)D * k * P * 8 / (double)((size_t)1 << 30);
   size_t chunk = D;
   if (chunk_env >= 64) chunk = (size_t)chunk_env;
@@ -1579,6 +1703,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
       w->events.push_back(e);
     }
   }
+  auto chunks = [&]() -> int32_t {
   for (size_t i = 0; i < nch; ++i) {
     const size_t d0 = i * chunk, cnt = (D - d0) < chunk ? (D - d0) : chunk;
     u64* nz = d_noisy + d0 * P;
@@ -1604,6 +1729,14 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
     PVW_HIP(hipStreamWaitEvent(s, w->events[nch], 0));
   }
   return PVW_OK;
+  };
+  int32_t rc = chunks();
+  if (rc != PVW_OK) {                       // nothing of a failed call stays queued behind the caller's back
+    if (w->aux) hipStreamSynchronize(w->aux);
+    hipStreamSynchronize(s);
+  }
+  int32_t rw = wipe_shat(c, w, s);          // every decrypt_mac launch above is on `s`
+  return rc != PVW_OK ? rc : rw;
 }
 
 int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, const uint64_t* c2col, size_t D,
@@ -1650,6 +1783,11 @@ int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, co
                            hipStreamSynchronize(w->stream) != hipSuccess))
         rc = fail(PVW_ERR_INTERNAL, "D2H failed");
     }
+    // the uploaded coefficients and NTT(sk) do not outlive the call (secret_key.rs:20-30)
+    ws_mark_secret(w, d_sk, k * l * 8);
+    ws_mark_secret(w, w->rhat, k * P * 8);
+    if ((ws_wipe_secrets(w, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) && rc == PVW_OK)
+      rc = fail(PVW_ERR_INTERNAL, "wipe failed");
   }
   ws_release(c, w);
   return rc;
@@ -1689,6 +1827,9 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
   u64* d_erow = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + b_rows);
   u64* d_xm = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + 2 * b_rows);
   u64* d_tmp = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + 2 * b_rows + b_xm);
+  // everything derived from the secret keys: their coefficients (and explicit key errors), NTT(s) rows, the
+  // sampled / transformed errors and the MFMA-tiled copy of NTT(s) -- cleared by pvw_keygen when the call ends
+  ws_mark_secret(w, d_small2[0], 2 * b_small + 2 * b_rows + b_xm);
   // the secret keys of chunk i+1 are uploaded on a helper stream while chunk i computes
   const u32 nchunks = (b - a + chunk - 1) / chunk;
   if (!w->aux) PVW_HIP(hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking));
@@ -1748,8 +1889,18 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
       PVW_HIP(hipEventRecord(w->events[2 * ci + 2], w->aux));
     }
   }
-  PVW_HIP(hipStreamSynchronize(s));
   return PVW_OK;
+}
+
+// single exit of a key generation: both streams are drained whatever happened (an early return must not leave
+// copies from the caller's sk / ek buffers or launches on pooled scratch in flight), the secret-bearing
+// regions are cleared, and only then does the workspace go back to the pool
+static int32_t keygen_finish(Workspace* w, int32_t rc) {
+  if (w->aux && hipStreamSynchronize(w->aux) != hipSuccess && rc == PVW_OK) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");
+  if (hipStreamSynchronize(w->stream) != hipSuccess && rc == PVW_OK) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");
+  if ((ws_wipe_secrets(w, w->stream) != hipSuccess || hipStreamSynchronize(w->stream) != hipSuccess) && rc == PVW_OK)
+    rc = fail(PVW_ERR_INTERNAL, "wipe failed");
+  return rc;
 }
 
 int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, const int64_t* ek, const uint8_t seed[32]) {
@@ -1769,13 +1920,13 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   hipStream_t s = w->stream;
   // >= 8 parties: the matrix cores (gemm_digits, 16 parties per pass over A^T, everything around it batched
   // over super-groups of up to 128 parties); fewer: 4 per pass on the VALU
-  const int gemm_min = [] { const char* e = getenv("PVW_GEMM_MIN_DEALERS"); return e ? atoi(e) : 8; }();
+  const int gemm_min = (int)PVW_ENV_INT("PVW_GEMM_MIN_DEALERS", 8);   // tuning build only
   const bool use_gemm = gemm_min > 0 && (b - a) >= (u32)gemm_min;
   // default matrix-core form: parties as GEMM rows, the CRS columns digitised once (PVW_KEYGEN_SWAP=0: the earlier
   // form with the transposed CRS as the streamed operand and the secret keys digitised per super-group)
-  const int swap_roles = [] { const char* e = getenv("PVW_KEYGEN_SWAP"); return e ? atoi(e) : 1; }();   // per call: the tests walk both
+  const int swap_roles = (int)PVW_ENV_INT("PVW_KEYGEN_SWAP", 1);   // tuning build, per call: the tests walk both
   if (use_gemm && swap_roles && (b - a) >= 64) {
-    int32_t rc2 = keygen_gemm_swapped(c, w, a, b, lo, sk, ek, seed);
+    int32_t rc2 = keygen_finish(w, keygen_gemm_swapped(c, w, a, b, lo, sk, ek, seed));
     ws_release(c, w);
     if (rc2 == PVW_OK && hi > c->num_keys) c->num_keys = hi;
     return rc2;
@@ -1816,6 +1967,12 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
     u64* d_vh = (u64*)gb0;
     signed char* d_yd = (signed char*)(gb0 + b_vh);
     int* d_sy = (int*)(gb0 + b_vh + b_yd);
+    // secret-bearing regions (cleared by keygen_finish): uploaded sk / ek coefficients; NTT(s) vectors, their digit
+    // tiles and column sums (matrix-core form) or the s-hat vectors in w->rhat (VALU form).  d_row holds e only
+    // until the product is added onto it, then rows of the public key.
+    ws_mark_secret(w, d_small, b_small);
+    if (use_gemm) ws_mark_secret(w, d_vh, b_vh + b_yd + b_sy);
+    else ws_mark_secret(w, w->rhat, w->rhat_bytes);
     // A -> API layout -> transpose polynomials (A^T[c][j] = A[j][c]) -> tiled / MFMA-tiled
     bool okk = launch_untile(c->dA, d_api, k, 0, k, L, l, false, c->dt, s) == hipSuccess;
     okk = okk && launch_transpose_polys(d_api, d_apiT, k, (u32)P, s) == hipSuccess;
@@ -1890,8 +2047,8 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
       if (!use_gemm) ok2 = ok2 && launch_tile(d_row, c->dB, nv, p0 - c->party_lo, k, L, l, false, c->dt, s) == hipSuccess;
       if (!ok2) rc = fail(PVW_ERR_KEY_GENERATION, "keygen launch failed");
     }
-    if (rc == PVW_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");
   }
+  rc = keygen_finish(w, rc);
   ws_release(c, w);
   if (rc == PVW_OK && hi > c->num_keys) c->num_keys = hi;
   return rc;

@@ -6,6 +6,24 @@
 #include "pvw_chacha.h"
 #include "pvw_decode.h"
 
+// PVW_TUNING selects the MEASUREMENT build (libpvw_hip_tuning.so, pvw_rs_amd/build.py): only there are the
+// timing / ablation switches (PVW_PROLOGUE_DEBUG, PVW_GEMM_DEBUG, PVW_DECODE_TIMING, -DPVW_GEMM_ABLATE), the
+// schedule selectors (PVW_MAC_VARIANT, PVW_DEC_VARIANT, PVW_DECODE_VARIANT, ...), the measured-and-rejected kernel
+// forms they select and the read-bandwidth probe compiled in.  The shipped library (PVW_TUNING 0) holds the
+// shape-selected schedules only and reads NO environment variable: nothing outside the arguments of a call can
+// change what it computes (the reference samples unconditionally, src/crypto/encryption.rs:135-167).
+#ifndef PVW_TUNING
+#define PVW_TUNING 0
+#endif
+#if PVW_TUNING
+#include <cstdlib>
+#define PVW_ENV_INT(name, dflt) ([]() -> long { const char* e_ = getenv(name); return e_ ? atol(e_) : (long)(dflt); }())
+#define PVW_PDBG(b, bit) (((b).debug & (bit)) != 0)
+#else
+#define PVW_ENV_INT(name, dflt) ((long)(dflt))
+#define PVW_PDBG(b, bit) false
+#endif
+
 namespace pvw {
 
 enum { DOM_R = 0, DOM_E1 = 1, DOM_E2 = 2, DOM_SK = 3, DOM_EKEY = 4, DOM_CRS = 5, DOM_GAUSS = 6, DOM_PK = 7 };
@@ -156,7 +174,11 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
                               hipStream_t s);
 // read-only probe: every wave streams `tiles` consecutive 1-KiB tiles (16 in flight), grid as mac_rows
+#if PVW_TUNING
 hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, hipStream_t s);
+#endif
+// per-device kernel attributes (dynamic-LDS limits); call once per context after hipSetDevice
+hipError_t init_kernel_attributes();
 hipError_t launch_mfma_probe(const signed char* A, const signed char* B, int* C, hipStream_t s);
 hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s);
 

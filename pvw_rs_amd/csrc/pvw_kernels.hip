@@ -18,8 +18,6 @@
 //   the rest      O(n + k) polynomials, launch-latency sized
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "pvw_arith.h"
 #include "pvw_chacha.h"
 #include "pvw_decode.h"
@@ -185,6 +183,7 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
   }
 }
 
+#if PVW_TUNING
 // mac_rows, continuous-stream schedule: the B-hat tile stream of a wave never drains at an r-hat chunk
 // boundary.  The r-hat slice of the NEXT chunk is fetched into registers one group ahead (so its loads
 // sit in front of the tile prefetch in the in-order vmcnt queue) and dropped into the wave-private LDS
@@ -312,6 +311,8 @@ __global__ __launch_bounds__(256) void mac_rows_stream_kernel(MacSection sa, Mac
     }
   }
 }
+
+#endif  // PVW_TUNING
 
 // ------------------------------------------------------------------------------------
 // mac_rows_multi: NV vectors against one pass over the tiled matrix,
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
     for (u32 x = 0; x + 1 < PVW_MAX_PROLOGUE_JOBS; ++x)
       if (ji == x && x + 1 < b.njobs && local >= b.job[x].sj.count) { local -= b.job[x].sj.count; ji = x + 1; }
   };
-  if (tid < PB && tid < 64 && gp0 + tid < b.total && !(b.debug & 1)) {
+  if (tid < PB && tid < 64 && gp0 + tid < b.total && !PVW_PDBG(b, 1)) {
     u32 ji, local;
     locate(gp0 + tid, ji, local);
     const PrologueJob& job = b.job[ji];
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
     }
   }
   __syncthreads();
-  if (b.debug & 2) return;
+  if (PVW_PDBG(b, 2)) return;
   const u32 n = L * ELL;
   // one thread per (polynomial, limb); a block of PB <= 64 polynomials takes ceil(PB * L / 256) trips
   for (u32 idx = tid; idx < PB * L; idx += 256) {
@@ -1376,7 +1377,8 @@ __global__ __launch_bounds__(256) void decode_wave_kernel(const u64* __restrict_
 template <int WPC>
 __global__ __launch_bounds__(512) void decode_chain_kernel(const u64* __restrict__ noisy, u64* __restrict__ out,
                                                             u32 count, u32 cpw_dbg, DecodeTables t) {
-  const u32 cpw = cpw_dbg & 0xffff, dbg = cpw_dbg >> 16;   // dbg != 0: timing experiment, out[] = cycle counts
+  const u32 cpw = cpw_dbg & 0xffff;
+  const u32 dbg = PVW_TUNING ? (cpw_dbg >> 16) : 0;        // tuning build, dbg != 0: timing experiment, out[] = cycle counts
   const u64 tk0 = dbg ? clock64() : 0;
   // LDS: CRT table [L][W] | two reciprocals, 2W+2 words each | per ciphertext: lifts [l+1][64] + signs, residues [L][l]
   //      | per wave: 64-word scratch
@@ -1738,6 +1740,9 @@ __device__ __forceinline__ int xor_lane_dpp(int v, int d) {
   return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, false);                // quad_perm [3,2,1,0]
 }
 
+#if !PVW_TUNING
+#undef PVW_GEMM_ABLATE
+#endif
 #ifndef PVW_GEMM_ABLATE
 #define PVW_GEMM_ABLATE 0
 #endif
@@ -1745,9 +1750,10 @@ __device__ __forceinline__ int xor_lane_dpp(int v, int d) {
 template <int ELL, int NVG, int RPW, int NCH = 0, bool FASTQ = false>
 __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
                                                            const int* __restrict__ SY, const Mod* __restrict__ mods,
-                                                           u32 k, u32 L, u32 nv_total, u32 nv_pad, u32 dbg, u32 vbn,
+                                                           u32 k, u32 L, u32 nv_total, u32 nv_pad, u32 dbg_arg, u32 vbn,
                                                            size_t yd_b16, size_t sy_b16) {
-  // dbg (PVW_GEMM_DEBUG, timing experiments only, results wrong): 1 = no K loop, 2 = no epilogue;
+  const u32 dbg = PVW_TUNING ? dbg_arg : 0;                // the shipped build has no timing branches
+  // dbg (tuning build: PVW_GEMM_DEBUG, timing experiments only, results wrong): 1 = no K loop, 2 = no epilogue;
   // compile-time ablations -DPVW_GEMM_ABLATE=bits: 8 = no A loads, 16 = no B loads, 32 = no MFMA
   // block = (limb, slot, group of 4*RPW row tiles); the 4 waves share the vector-digit tiles through
   // LDS (CJ j-blocks at a time); each wave owns RPW row tiles of 32 rows and streams their raw u64 tiles.
@@ -2045,6 +2051,7 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
     }
 }
 
+#if PVW_TUNING
 // ------------------------------------------------------------------------------------
 // read-bandwidth probe (self-test / measurement aid): the loads of mac_rows -- 1-KiB tiles, 16 bytes per lane,
 // non-temporal, 16 in flight per wave, four waves per workgroup on one contiguous run -- with the arithmetic
@@ -2070,6 +2077,8 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const u64* __restrict__
   if ((acc.x ^ acc.y) == 0x9e3779b97f4a7c15ULL) sink[blockIdx.x] = acc.x;   // keeps the loads alive
 }
 
+#endif  // PVW_TUNING
+
 // ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
@@ -2082,17 +2091,18 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const u64* __restrict__
     default: return hipErrorInvalidValue;                \
   }
 
-// PVW_MAC_VARIANT (debug/tuning): selects the streaming schedule of mac_rows for l = 8 / 16
+// PVW_MAC_VARIANT (tuning build only): selects the streaming schedule of mac_rows for l = 8 / 16
 //   0 (default) by shape, see below | 17 U=8 (l=8) / 16 (l=16) double-buffered nt, not interleaved | 1 same, default cache policy | 2 U=4 dbuf nt | 3 U=16 dbuf nt
 //   4 U=16 single buffer nt | 5 U=8 single buffer nt | 6 U=16 single buffer, default policy
 //   7 continuous stream U=8 nt | 8 continuous stream U=16 nt | 9/10/11 waves interleave groups of U=8/16/4 tiles | 18/19 interleaved, single buffer, U=16/8
+// The shipped library has the shape-selected schedule only (and no environment lookup).
 static int mac_variant() {   // read per launch: the parity tests walk the variants in one process
-  const char* e = getenv("PVW_MAC_VARIANT");
-  return e ? atoi(e) : 0;
+  return (int)PVW_ENV_INT("PVW_MAC_VARIANT", 0);
 }
 template <int E>
 static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacSection& sa, const MacSection& sb,
                                const u64* rhat, const Mod* mods, u32 k, u32 L) {
+#if PVW_TUNING
   if constexpr (E <= 16) {
     switch (variant) {
       case 1: mac_rows_kernel<E, 8, false, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
@@ -2116,6 +2126,7 @@ static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacS
       default: break;
     }
   }
+#endif
   // defaults from the round-1 sweeps (profiles/r01_variant_sweep.txt, r01d_mac_ilv_sweep.txt): always
   // double-buffered non-temporal loads; when k allows it the four waves interleave groups of 16 tiles so the
   // workgroup reads one contiguous stream (+5 % at l = 16, k = 512; +2 % at n = 16384; within noise at config 3)
@@ -2229,8 +2240,7 @@ hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJo
 hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s) {
   PrologueBatch b = batch;
   b.total = 0;
-  static u32 dbg = [] { const char* e = getenv("PVW_PROLOGUE_DEBUG"); return e ? (u32)atoi(e) : 0u; }();
-  b.debug = dbg;   // timing experiments only: 1 = skip sampling, 2 = skip transform
+  b.debug = (u32)PVW_ENV_INT("PVW_PROLOGUE_DEBUG", 0);   // tuning build only (timing experiments: 1 = skip sampling, 2 = skip transform); the shipped kernel has neither branch
   if (b.njobs > PVW_MAX_PROLOGUE_JOBS) return hipErrorInvalidValue;
   if (b.reps == 0) b.reps = 1;
   if (b.reps > 65535) return hipErrorInvalidValue;
@@ -2281,9 +2291,7 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
   // variant 0 (default) picks by shape: the full-width form from 128 slot pairs per polynomial up, the
   // dealer-grouped form below that (profiles/r01_variant_sweep.txt, profiles/r01d_decrypt_sweep.txt).
   // The environment is read on every launch so that the tests can walk the variants in one process.
-  int variant = 0, cenv = 0;
-  if (const char* e = getenv("PVW_DEC_VARIANT")) variant = atoi(e);
-  if (const char* e = getenv("PVW_DEC_C")) cenv = atoi(e);
+  int variant = (int)PVW_ENV_INT("PVW_DEC_VARIANT", 0), cenv = (int)PVW_ENV_INT("PVW_DEC_C", 0);   // tuning build only
   if (variant == 0) variant = pairs >= 128 && pairs <= 1024 ? 61 : 10;
   if (variant < 60 && pairs <= 1024 && cenv > 0 && (u32)cenv * pairs <= 1024 && (u32)cenv <= k) {
     c = (u32)cenv;
@@ -2313,6 +2321,7 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
 #define PVW_DEC_FW(DGv, UJv)                                                                                       \
   decrypt_mac_fw_kernel<DGv, UJv><<<dim3((u32)((dealers + DGv - 1) / DGv)), dim3(thr), (size_t)DGv * thr * sizeof(v2u64), s>>>( \
       c1s, shat, c2col, noisy, t.mods, k, ell, pairs, FW, cfull, remp, crem, (u32)dealers)
+#if PVW_TUNING
       switch (variant) {
         case 61: PVW_DEC_FW(2, 4); break;
         case 62: PVW_DEC_FW(1, 4); break;
@@ -2320,6 +2329,9 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
         case 64: PVW_DEC_FW(3, 2); break;
         default: PVW_DEC_FW(2, 2); break;
       }
+#else
+      PVW_DEC_FW(2, 4);
+#endif
 #undef PVW_DEC_FW
       return hipGetLastError();
     }
@@ -2335,6 +2347,7 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
       decrypt_mac_grouped_kernel<DGv, UJv, 1024><<<dim3((u32)((dealers + DGv - 1) / DGv)), dim3(threads), lds, s>>>( \
           c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers);                                \
   } while (0)
+#if PVW_TUNING
     switch (variant) {
       case 10: PVW_DEC_GROUPED(2, 2); break;
       case 11: PVW_DEC_GROUPED(2, 4); break;
@@ -2349,6 +2362,9 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
         break;
       default: PVW_DEC_GROUPED(2, 2); break;
     }
+#else
+    PVW_DEC_GROUPED(2, 2);
+#endif
 #undef PVW_DEC_GROUPED
     return hipGetLastError();
   }
@@ -2357,6 +2373,7 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
     const u64* c1p = c1s + off * (size_t)k * L * ell;
     const u64* c2p = c2col + off * (size_t)L * ell;
     u64* np = noisy + off * (size_t)L * ell;
+#if PVW_TUNING
     switch (variant) {
       case 1: decrypt_mac_kernel<4, false><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
       case 2: decrypt_mac_kernel<8, false><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
@@ -2364,6 +2381,9 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
       case 4: decrypt_mac_kernel<2, true><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
       default: decrypt_mac_kernel<4, true><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step); break;
     }
+#else
+    decrypt_mac_kernel<4, true><<<dim3(nd, ny), dim3(threads), lds, s>>>(c1p, shat, c2p, np, t.mods, k, ell, pairs, c, step);
+#endif
   }
   return hipGetLastError();
 }
@@ -2399,9 +2419,14 @@ hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, i
     if (e != hipSuccess) return e;
   }
   // default: stores staged through LDS (whole 128-byte lines per instruction, 16 KiB per wave); PVW_VEC_DIGITS_STAGE=0: direct
-  static int stage = [] { const char* e = getenv("PVW_VEC_DIGITS_STAGE"); return e ? atoi(e) : 1; }();
-  if (stage) { PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, true><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t, lstride, jstride)); }
-  else { PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, false><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t, lstride, jstride)); }
+#if PVW_TUNING
+  static const int stage = (int)PVW_ENV_INT("PVW_VEC_DIGITS_STAGE", 1);
+  if (!stage) {
+    PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, false><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t, lstride, jstride));
+    return hipGetLastError();
+  }
+#endif
+  PVW_DISPATCH_ELL(ell, vec_digits_kernel<E, true><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t, lstride, jstride));
   return hipGetLastError();
 }
 
@@ -2419,15 +2444,14 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   sa.tmp_bstride = (size_t)L * ell * 16 * sa.rt_groups * PVW_GEMM_ROWS_PER_WG;
   sb.tmp_bstride = (size_t)L * ell * 16 * sb.rt_groups * PVW_GEMM_ROWS_PER_WG;
   const size_t yd_b16 = yd_bytes(16, k, L, ell), sy_b16 = sy_bytes(16, L, ell) / sizeof(int);
-  u32 dbg = 0;
-  if (const char* e = getenv("PVW_GEMM_DEBUG")) dbg = (u32)atoi(e);
+  const u32 dbg = (u32)PVW_ENV_INT("PVW_GEMM_DEBUG", 0);   // tuning build only; the shipped kernel ignores the argument
 #define PVW_GEMM_LAUNCH(G, N)                                                                                              \
   do {                                                                                                                    \
     if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, true><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16)); } \
     else { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, false><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16)); } \
   } while (0)
   // fully unrolled chunk loops for the BASELINE geometries (k = 256: 8 chunks of 8 j-blocks, k = 512: 16), full vector groups
-  static int unroll_ok = [] { const char* e = getenv("PVW_GEMM_UNROLL"); return e ? atoi(e) : 1; }();
+  static const int unroll_ok = (int)PVW_ENV_INT("PVW_GEMM_UNROLL", 1);
   if (NVG == 4 && unroll_ok && !(dbg & 1) && k == 256) { PVW_GEMM_LAUNCH(4, 8); }
   else if (NVG == 4 && unroll_ok && !(dbg & 1) && k == 512) { PVW_GEMM_LAUNCH(4, 16); }
   else switch (NVG) {
@@ -2449,6 +2473,7 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   return hipGetLastError();
 }
 
+#if PVW_TUNING
 hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, hipStream_t s) {
   if (total_tiles == 0 || tiles_per_wave < 16) return hipErrorInvalidValue;
   const size_t per_wg = (size_t)4 * tiles_per_wave;
@@ -2456,45 +2481,57 @@ hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wav
   read_probe_kernel<<<dim3(blocks), dim3(256), 0, s>>>(M, total_tiles, tiles_per_wave, sink);
   return hipGetLastError();
 }
+#endif  // PVW_TUNING
 
 hipError_t launch_mfma_probe(const signed char* A, const signed char* B, int* C, hipStream_t s) {
   mfma_i8_probe_kernel<<<dim3(1), dim3(64), 0, s>>>(A, B, C);
   return hipGetLastError();
 }
 
+// Kernels that may ask for more than the default 64 KiB of dynamic LDS.  The attribute is per device and per
+// code object, so it is set once per CONTEXT while the context initialises its device (ensure_device, under the
+// context's init mutex, after hipSetDevice) -- not lazily behind process-wide flags.
+hipError_t init_kernel_attributes() {
+  const int big = 160 * 1024;
+  hipError_t e = hipFuncSetAttribute((const void*)decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)decode_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)decode_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e != hipSuccess) return e;
+#if PVW_TUNING
+  e = hipFuncSetAttribute((const void*)decode_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)decode_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e != hipSuccess) return e;
+#endif
+  return hipSuccess;
+}
+
 hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s) {
   if (count == 0) return hipSuccess;
   const size_t lds = (size_t)(2 * t.W + 1 + t.L) * 64 * sizeof(u64);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  // PVW_DECODE_VARIANT: 0 (default) lifted chain, 4 waves per ciphertext | 1 thread per ciphertext |
-  //   2 one wave per ciphertext (RNS round trip per step) | 3 / 4 lifted chain with 2 / 8 waves per ciphertext
-  int variant = 0;
-  if (const char* e = getenv("PVW_DECODE_VARIANT")) variant = atoi(e);
+  // by shape: the lifted chain (4 waves per ciphertext) while L <= 64 and W + 2 <= 63 (Q up to ~3900 bits) and its
+  // tables fit the LDS; one wave per ciphertext below W + 2 <= 64; one thread per ciphertext beyond.
+  // tuning build: PVW_DECODE_VARIANT 1 thread per ciphertext | 2 one wave per ciphertext (RNS round trip per step)
+  //   | 3 / 4 lifted chain with 2 / 8 waves per ciphertext
+  const int variant = (int)PVW_ENV_INT("PVW_DECODE_VARIANT", 0);
   if ((variant == 0 || variant >= 3) && t.L <= 64 && t.W + 2 <= 63) {
     const u32 wpc = variant == 3 ? 2 : (variant == 4 ? 8 : 4);
     const u32 cpw = 8 / wpc ? 8 / wpc : 1;
     const size_t bytes = ((size_t)t.L * t.W + 2 * (2 * t.W + 2) + (size_t)cpw * ((size_t)(t.ell + 1) * 64 + (size_t)t.L * t.ell) +
                           (size_t)cpw * wpc * 64) * 8;
     if (bytes <= 160 * 1024) {
-      static bool cattr = false;
-      if (!cattr) {
-        hipFuncSetAttribute((const void*)decode_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)decode_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)decode_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        cattr = true;
-      }
       const dim3 grid((u32)((count + cpw - 1) / cpw)), block(cpw * wpc * 64);
-      u32 dbg = 0;   // PVW_DECODE_TIMING=1|2|3: out[] = cycles of phase 1 | first division | chain (results are NOT values)
-      if (const char* e = getenv("PVW_DECODE_TIMING")) dbg = (u32)atoi(e);
+      // tuning build only: PVW_DECODE_TIMING=1|2|3: out[] = cycles of phase 1 | first division | chain (results are NOT values)
+      const u32 dbg = (u32)PVW_ENV_INT("PVW_DECODE_TIMING", 0);
       const u32 arg = cpw | (dbg << 16);
-      if (wpc == 2) decode_chain_kernel<2><<<grid, block, bytes, s>>>(noisy, out, (u32)count, arg, t);
-      else if (wpc == 8) decode_chain_kernel<8><<<grid, block, bytes, s>>>(noisy, out, (u32)count, arg, t);
-      else decode_chain_kernel<4><<<grid, block, bytes, s>>>(noisy, out, (u32)count, arg, t);
+#if PVW_TUNING
+      if (wpc == 2) { decode_chain_kernel<2><<<grid, block, bytes, s>>>(noisy, out, (u32)count, arg, t); return hipGetLastError(); }
+      if (wpc == 8) { decode_chain_kernel<8><<<grid, block, bytes, s>>>(noisy, out, (u32)count, arg, t); return hipGetLastError(); }
+#endif
+      decode_chain_kernel<4><<<grid, block, bytes, s>>>(noisy, out, (u32)count, arg, t);
       return hipGetLastError();
     }
   }
@@ -2502,11 +2539,6 @@ hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeT
     const size_t tab = ((size_t)2 * t.L * t.W + 4 * (t.W + 2)) * 8, scratch = (size_t)4 * 64 * 8, zb = (size_t)4 * t.L * t.ell * 8;
     const u32 stage_z = (tab + scratch + zb <= 96 * 1024) ? 1u : 0u;
     const size_t wl = tab + scratch + (stage_z ? zb : 0);
-    static bool wattr = false;
-    if (!wattr) {
-      hipFuncSetAttribute((const void*)decode_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      wattr = true;
-    }
     decode_wave_kernel<<<dim3((u32)((count + 3) / 4)), dim3(256), wl, s>>>(noisy, out, (u32)count, stage_z, t);
     return hipGetLastError();
   }

@@ -48,11 +48,11 @@ def load_broadcast_crs(params: PvwParameters, t, repr: int = _ffi.REPR_NTT) -> P
     import torch
     if t.is_cuda:
         stream = C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-        _check(_ffi.lib().pvw_load_crs_device(params._h, C.c_void_p(t.data_ptr()), repr, stream))
+        params._call("pvw_load_crs_device", C.c_void_p(t.data_ptr()), repr, stream)
         torch.cuda.synchronize(t.device)
     else:
         a = t.numpy().view(np.uint64)
-        _check(_ffi.lib().pvw_load_crs(params._h, a.ctypes.data_as(C.c_void_p), repr))
+        params._call("pvw_load_crs", a.ctypes.data_as(C.c_void_p), repr)
     return PvwCrs(params)
 
 

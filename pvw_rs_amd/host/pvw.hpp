@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <memory>
 #include <optional>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -147,6 +148,30 @@ class PvwCrs {
     check(pvw_crs_generate(p->ctx, seed.data()));
     return PvwCrs{p};
   }
+  // PvwCrs::new (crs.rs:24-39): a fresh random CRS; `rng` is any callable returning random 32-bit words
+  // (default: std::random_device, the OS entropy source -- the reference takes a CryptoRng)
+  template <class Rng>
+  static PvwCrs create(const std::shared_ptr<PvwParameters>& p, Rng& rng) {
+    Seed seed;
+    for (size_t i = 0; i < 32; i += 4) {
+      const uint32_t w = (uint32_t)rng();
+      for (size_t b = 0; b < 4; ++b) seed[i + b] = (uint8_t)(w >> (8 * b));
+    }
+    return new_deterministic(p, seed);
+  }
+  static PvwCrs create(const std::shared_ptr<PvwParameters>& p) {
+    std::random_device rd;
+    return create(p, rd);
+  }
+  // PvwCrs::new_from_tag (crs.rs:74-90): the seed is DefaultHasher(tag + "CRS"), 8 LE bytes repeated four times
+  static Seed seed_from_tag(const std::string& tag) {
+    Seed seed;
+    check(pvw_crs_seed_from_tag(tag.c_str(), seed.data()));
+    return seed;
+  }
+  static PvwCrs new_from_tag(const std::shared_ptr<PvwParameters>& p, const std::string& tag) {
+    return new_deterministic(p, seed_from_tag(tag));
+  }
   static PvwCrs from_polynomials(const std::shared_ptr<PvwParameters>& p, const std::vector<uint64_t>& a,
                                  uint32_t repr = PVW_REPR_POWER) {
     if (a.size() != (size_t)p->k * p->k * p->poly_words()) throw PvwError(15, "CRS size mismatch");
@@ -161,10 +186,22 @@ class SecretKey {
  public:
   std::shared_ptr<PvwParameters> params;
   std::vector<int64_t> secret_coeffs;   // [k][l]
+  SecretKey(std::shared_ptr<PvwParameters> p, std::vector<int64_t> c) : params(std::move(p)), secret_coeffs(std::move(c)) {}
+  SecretKey(const SecretKey&) = default;
+  SecretKey(SecretKey&&) = default;
+  SecretKey& operator=(const SecretKey&) = default;
+  SecretKey& operator=(SecretKey&&) = default;
+  ~SecretKey() { zeroize(); }                                   // ZeroizeOnDrop (secret_key.rs:20-30)
   static SecretKey random(const std::shared_ptr<PvwParameters>& p, const Seed& seed, uint32_t party_index) {   // :45-63
     SecretKey s{p, std::vector<int64_t>((size_t)p->k * p->l)};
     check(pvw_sample_secret_keys(p->ctx, seed.data(), party_index, 1, s.secret_coeffs.data()));
     return s;
+  }
+  // Zeroize: the coefficients are overwritten through a volatile pointer (not elided as a dead store); the device
+  // side clears its own copies before every key-bearing call returns (pvw_selftest_secret_residue)
+  void zeroize() {
+    volatile int64_t* p = secret_coeffs.data();
+    for (size_t i = 0; i < secret_coeffs.size(); ++i) p[i] = 0;
   }
   size_t len() const { return params->k; }
 };
@@ -196,7 +233,19 @@ class GlobalPublicKey {
   }
   void generate_all_party_keys(const std::vector<Party>& parties, const Seed& seed) {                  // :376-401
     if (parties.size() > params->n) throw PvwError(1, "Too many parties");
-    for (const Party& p : parties) generate_and_add_party(p, seed);
+    // every run of consecutive party indices is ONE batched device call (the reference generates in parallel and
+    // adds in order, :387-399)
+    for (size_t i = 0; i < parties.size();) {
+      size_t j = i + 1;
+      while (j < parties.size() && parties[j].index == parties[j - 1].index + 1) ++j;
+      std::vector<int64_t> sk;
+      for (size_t x = i; x < j; ++x) sk.insert(sk.end(), parties[x].secret_key.secret_coeffs.begin(), parties[x].secret_key.secret_coeffs.end());
+      const int32_t rc = pvw_keygen(params->ctx, parties[i].index, parties[i].index + (uint32_t)(j - i), sk.data(), nullptr, seed.data());
+      volatile int64_t* w = sk.data();
+      for (size_t x = 0; x < sk.size(); ++x) w[x] = 0;
+      check(rc);
+      i = j;
+    }
   }
   uint32_t num_public_keys() const { uint32_t v = 0; check(pvw_num_public_keys(params->ctx, &v)); return v; }   // :344
   bool is_full() const { int32_t v = 0; check(pvw_is_full(params->ctx, &v)); return v != 0; }                   // :349

@@ -53,6 +53,26 @@ int main() {
       return 1;
     } catch (const PvwError&) {}
     if (correct * 100 < total * 95) return 1;
+    // PvwCrs::new_from_tag (crs.rs:74-90) + generate_all_party_keys as ONE batched call (public_key.rs:376-401):
+    // same tag, same CRS; the batched keys decrypt what was encrypted to them
+    {
+      auto params2 = PvwParametersBuilder().set_parties(num_parties).set_dimension(4).set_l(16).set_moduli(moduli)
+                         .set_secret_variance(0.5f).set_error_bounds_u32(bound1, bound2).build_arc();
+      if (PvwCrs::seed_from_tag("host-roundtrip") != PvwCrs::seed_from_tag("host-roundtrip") ||
+          PvwCrs::seed_from_tag("host-roundtrip") == PvwCrs::seed_from_tag("another tag")) { printf("tag seed\n"); return 1; }
+      GlobalPublicKey gpk2(PvwCrs::new_from_tag(params2, "host-roundtrip"));
+      std::vector<Party> parties2;
+      for (uint32_t i = 0; i < num_parties; ++i) parties2.push_back(Party::create(i, params2, seed));
+      gpk2.generate_all_party_keys(parties2, seed);
+      if (!gpk2.is_full()) { printf("batched keygen: not full\n"); return 1; }
+      auto ct = encrypt_party_shares(all[3], 3, gpk2, seed);
+      uint32_t good = 0;
+      for (uint32_t i = 0; i < num_parties; ++i) good += decrypt_party_value(ct, parties2[i].secret_key, i) == all[3][i];
+      if (good * 100 < num_parties * 95) { printf("batched keygen round trip %u/%u\n", good, num_parties); return 1; }
+      SecretKey gone = parties2[0].secret_key;
+      gone.zeroize();
+      for (int64_t v : gone.secret_coeffs) if (v != 0) { printf("zeroize\n"); return 1; }
+    }
     printf("CPP_HOST_OK\n");
     return 0;
   } catch (const std::exception& e) {

@@ -61,3 +61,23 @@ def test_world2_gloo_cpu():
 @pytest.mark.gpu
 def test_world2_hip_on_one_gpu():
     _run("hip")
+
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    # `python bench.py --gpus 2` end to end: it launches torch.distributed.run itself (child process, one rank
+    # per "GPU"); rehearsed here with both ranks on cuda:0 and gloo for the barrier / max-reduce, because RCCL
+    # cannot put two ranks on one device.  Checks the ONE JSON line of rank 0.
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, PVW_BENCH_BACKEND="gloo", PVW_BENCH_SAME_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--config", "c2", "--no-cpu", "--sustain-seconds", "0.2"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size_observed"] == 2 and d["config"]["parties_total"] == 2048
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["roofline"]["frac"] > 0

@@ -108,6 +108,40 @@ def test_gaussian_contract():
     assert huge.tolist() == [M.sample_single_gaussian(10 ** 16, M.ChaChaRng(SEED, M.DOM_GAUSS, i)) for i in range(256)]
 
 
+def test_gaussian_box_muller_branch_moments_and_model_draws():
+    # normal.rs:165-190: for bound <= 5, sigma = bound/16.96 <= 0.3 and the ratio is a genuine Box-Muller draw
+    # z*sigma, rejected outside [-1, 1]; x = round(ratio*bound) = round(z * bound^2/16.96).  The reference's
+    # own moment check (tests/sampling.rs:114-129) asks |mean| < 0.2 and |var - 1| < 0.3 of N(0,1) on 1000 draws;
+    # here the expected moments of the ROUNDED variable are computed from the normal CDF and held to the same
+    # relative slack on 8192 draws per bound, and every draw is compared with the model's draw on the same
+    # ChaCha stream: libm's and the device's log / cos may differ in the last ulp, which can only matter when
+    # z*scale sits within ~1e-15 of a rounding boundary or of the rejection edge -- counted, and bounded.
+    import math
+    p = build_params(3, 4, 8, TEST_MODULI)
+    N = 8192
+    phi = lambda t: 0.5 * (1.0 + math.erf(t / math.sqrt(2.0)))
+    total_mismatch = 0
+    for bound in (1, 2, 3, 4, 5):
+        xs = p.sample_discrete_gaussian_vec(SEED, bound, N)
+        assert np.abs(xs).max() <= bound
+        scale = bound * bound / 16.96                       # x = round(z * scale), z truncated to |z| <= 16.96/bound
+        zmax = 16.96 / bound
+        norm = phi(zmax) - phi(-zmax)
+        probs = {}
+        for j in range(-bound, bound + 1):
+            lo, hi = max((j - 0.5) / scale, -zmax), min((j + 0.5) / scale, zmax)
+            probs[j] = max(phi(hi) - phi(lo), 0.0) / norm
+        var_want = sum(j * j * q for j, q in probs.items())
+        sd = math.sqrt(var_want) if var_want > 0 else 0.0
+        assert abs(xs.mean()) < 0.2 * max(sd, 0.05), (bound, xs.mean())
+        assert abs(xs.var() - var_want) < 0.3 * max(var_want, 0.01), (bound, xs.var(), var_want)
+        for j, q in probs.items():                           # the whole histogram, not only two moments
+            assert abs((xs == j).mean() - q) < 5.0 * math.sqrt(max(q * (1 - q), 1e-6) / N) + 1e-3, (bound, j)
+        want = [M.sample_single_gaussian(bound, M.ChaChaRng(SEED, M.DOM_GAUSS, i)) for i in range(N)]
+        total_mismatch += int((xs != np.array(want)).sum())
+    assert total_mismatch <= 2, f"{total_mismatch} of {5 * N} Box-Muller draws differ from the model"
+
+
 # ---------------------------------------------------------------- golden fixtures
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(g)[:-4] for g in GOLDEN])
 def test_golden_keygen_encrypt_decrypt(path):
@@ -299,9 +333,11 @@ def test_ragged_geometries_against_c_oracle(n, k, l, L):
     assert np.array_equal(noisy, orc.decrypt_noisy(sk, c1s, c2col))
 
 
-@pytest.mark.parametrize("n,k,l,L", [(40, 256, 8, 3), (21, 128, 16, 2), (9, 64, 8, 2), (5, 24, 8, 2)])
-def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
-    # every streaming schedule of mac_rows (PVW_MAC_VARIANT) computes the same c1, c2 (encryption.rs:158,177-200)
+MAC_SCHEDULE_CASES = [(40, 256, 8, 3), (21, 128, 16, 2), (9, 64, 8, 2), (5, 24, 8, 2)]
+
+
+def mac_rows_case(n, k, l, L):
+    """(encrypt closure, oracle c1, oracle c2) for one geometry: c1, c2 of encryption.rs:158,177-200"""
     moduli = M.bench_moduli(L)
     p = build_params(n, k, l, moduli)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
@@ -314,23 +350,28 @@ def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
     e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
     e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
     c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), np.array(scalars, dtype=np.uint64), r, e1, e2)
-    for variant in range(0, 20):
-        monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
-        ct = P.encrypt(scalars, gpk, SEED)
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
+    return (lambda: P.encrypt(scalars, gpk, SEED)), c1o, c2o
 
 
-@pytest.mark.parametrize("k,l,L,D", [
+@pytest.mark.parametrize("n,k,l,L", MAC_SCHEDULE_CASES)
+def test_mac_rows_shape_selected_schedule_agrees_with_c_oracle(n, k, l, L):
+    # the schedule the shipped library picks by shape (every other one: tests/test_gpu_tuning.py)
+    run, c1o, c2o = mac_rows_case(n, k, l, L)
+    ct = run()
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+
+
+DECRYPT_SHAPE_CASES = [
     (37, 16, 34, 5),      # 272 slot pairs (configs 4/5): four full waves + a 16-pair remainder wave
     (20, 32, 9, 4),       # 144 pairs: two full waves + remainder
     (64, 8, 17, 7),       # 68 pairs (configs 2/3): one full wave + a 4-pair remainder
     (9, 8, 3, 3),         # 12 pairs: remainder waves only
     (11, 16, 8, 2),       # 64 pairs: no remainder
-])
-def test_decrypt_mac_launch_shapes_agree_with_c_oracle(k, l, L, D, monkeypatch):
-    # every launch shape of decrypt_party_value's <sk, c1> (decryption.rs:271-291) gives the oracle's
-    # noisy polynomials: the shape-selected default, the dealer-grouped form and the full-width form,
-    # each with 1, 2, 3 j-replicas
+]
+
+
+def decrypt_mac_case(k, l, L, D):
+    """(closure returning the noisy polynomials, oracle's) for decrypt_party_value's <sk, c1> - c2 (decryption.rs:257-274)"""
     moduli = M.bench_moduli(L)
     p = build_params(3, k, l, moduli)
     orc = O.Oracle(moduli, l)
@@ -340,19 +381,25 @@ def test_decrypt_mac_launch_shapes_agree_with_c_oracle(k, l, L, D, monkeypatch):
     want = orc.decrypt_noisy(sk, c1s, c2col)
     cts = [P.PvwCiphertext(c1s[d], np.repeat(c2col[d][None], 3, axis=0), p, P.REPR_NTT) for d in range(D)]
     key = P.SecretKey.from_coefficients(p, sk)
-    for variant, c in [(0, 0), (10, 0), (10, 2), (10, 3), (11, 0), (60, 0), (60, 1), (60, 2), (61, 3), (62, 0), (64, 0)]:
-        monkeypatch.setenv("PVW_DEC_VARIANT", str(variant))
-        monkeypatch.setenv("PVW_DEC_C", str(c))
-        _, noisy = P.api._decrypt_batch(p, cts, key, 0, return_noisy=True)
-        assert np.array_equal(noisy, want), (variant, c)
+    return (lambda: P.api._decrypt_batch(p, cts, key, 0, return_noisy=True)[1]), want
+
+
+@pytest.mark.parametrize("k,l,L,D", DECRYPT_SHAPE_CASES)
+def test_decrypt_mac_shape_selected_launch_agrees_with_c_oracle(k, l, L, D):
+    # the launch shape the shipped library picks (the others: tests/test_gpu_tuning.py)
+    run, want = decrypt_mac_case(k, l, L, D)
+    assert np.array_equal(run(), want)
 
 
 @pytest.mark.parametrize("D", [1, 2, 4, 7])
-@pytest.mark.parametrize("gemm_from", [0, 3])
-def test_multi_dealer_encrypt_equals_separate_encrypts(D, gemm_from, monkeypatch):
-    # encrypt_all_party_shares (encryption.rs:253-286): the integer-VALU form (four dealers per pass over B-hat;
-    # forced everywhere with PVW_GEMM_MIN_DEALERS=0) and the default split (matrix cores from 3 dealers up)
-    monkeypatch.setenv("PVW_GEMM_MIN_DEALERS", str(gemm_from))
+def test_multi_dealer_encrypt_equals_separate_encrypts(D):
+    # encrypt_all_party_shares (encryption.rs:253-286) with the shipped split: the integer-VALU form (several
+    # dealers per pass over B-hat) below 3 dealers, the matrix cores from 3 up (VALU form forced everywhere:
+    # tests/test_gpu_tuning.py)
+    multi_dealer_case(D)
+
+
+def multi_dealer_case(D):
     n, k, l, moduli = 13, 9, 8, M.bench_moduli(4)
     p = build_params(n, k, l, moduli)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
@@ -395,6 +442,17 @@ def test_digit_gemm_multi_dealer_equals_separate_encrypts(n, k, l, L, D):
         one = P.encrypt(rows[d], gpk, seeds[d])
         assert np.array_equal(many[d].c1, one.c1), f"c1 dealer {d}"
         assert np.array_equal(many[d].c2, one.c2), f"c2 dealer {d}"
+    # ... and against the C restatement itself (not only the single-dealer HIP path): first, middle and last dealer
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(SEED, M.DOM_CRS, 0, k * k).reshape(k, k, L, l)
+    b_hat = orc.fill_uniform(SEED, M.DOM_PK, 0, n * k).reshape(n, k, L, l)
+    g_hat = p.gadget_polynomial(P.REPR_NTT)
+    for d in sorted({0, D // 2, D - 1}):
+        r = O.sample_cbd(seeds[d], M.DOM_R, 0, k, l, 0.5)
+        e1 = O.sample_uniform(seeds[d], M.DOM_E1, 0, k, l, 100)
+        e2 = O.sample_uniform(seeds[d], M.DOM_E2, 0, n, l, 200)
+        c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, np.array(rows[d], dtype=np.uint64), r, e1, e2)
+        assert np.array_equal(many[d].c1, c1o) and np.array_equal(many[d].c2, c2o), f"dealer {d} vs oracle"
 
 
 def test_multi_dealer_encrypt_l16_and_sharded():
@@ -415,7 +473,11 @@ def test_multi_dealer_encrypt_l16_and_sharded():
 
 @pytest.mark.parametrize("l,moduli", [(8, [0xFFFFEE001]), (8, TEST_MODULI), (32, TEST_MODULI), (8, M.bench_moduli(17)),
                                       (16, M.bench_moduli(34)), (64, primes_1mod(128, 5))])
-def test_device_decode_matches_model(l, moduli, monkeypatch):
+def test_device_decode_matches_model(l, moduli):
+    device_decode_case(l, moduli, lambda variant: None, (0,))
+
+
+def device_decode_case(l, moduli, select_variant, variants):
     # decode_scalar_pvw_rns (decryption.rs:10-58) on the device, fixed-width integers
     rng = np.random.default_rng(l + len(moduli))
     p = build_params(3, 4, l, moduli)
@@ -434,10 +496,10 @@ def test_device_decode_matches_model(l, moduli, monkeypatch):
     arr = np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64)
     want = [M.decode_scalar_pvw(z, m) for z in cases]
     assert want == P.decode_scalar_pvw_host(p, arr)
-    # every device form: lifted chain with 4 / 2 / 8 waves per ciphertext, one wave per ciphertext with an
-    # RNS round trip per step, one thread per ciphertext
-    for variant in (0, 3, 4, 2, 1):
-        monkeypatch.setenv("PVW_DECODE_VARIANT", str(variant))
+    # the shipped library picks the form by shape (lifted chain, 4 waves per ciphertext, for every Q here); the
+    # tuning build walks the others: 2 / 8 waves, one wave per ciphertext with an RNS round trip per step, one thread
+    for variant in variants:
+        select_variant(variant)
         assert P.decode_scalar_pvw(p, arr) == want, variant
 
 
@@ -476,14 +538,12 @@ def test_concurrent_encrypt_calls_on_one_context():
 def test_mfma_i8_operand_maps():
     # exact-integer check of the lane maps the digit-GEMM kernels rely on (asymmetric operands)
     import ctypes as C
-    from pvw_rs_amd import _ffi
     p = build_params(3, 4, 8, TEST_MODULI)
     rng = np.random.default_rng(5)
     a = rng.integers(-128, 128, size=(32, 32), dtype=np.int8)
     b = rng.integers(-128, 128, size=(32, 32), dtype=np.int8)
     out = np.zeros((32, 32), dtype=np.int32)
-    P.api._check(_ffi.lib().pvw_selftest_mfma_i8(p._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
-                                                out.ctypes.data_as(C.c_void_p)))
+    p._call("pvw_selftest_mfma_i8", a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert np.array_equal(out, a.astype(np.int32) @ b.astype(np.int32))
 
 
@@ -608,14 +668,20 @@ def test_random_geometries_full_pipeline_against_c_oracle(case):
             assert sum(v == rows[d][i] for d, v in enumerate(vals)) >= 0.95 * D - 1
 
 
-@pytest.mark.parametrize("swap,n,k,l,L", [(1, 150, 256, 8, 2), (0, 150, 256, 8, 2), (1, 70, 9, 8, 3), (1, 1100, 32, 16, 2),
-                                                 (1, 3100, 8, 8, 2)])    # four 1024-party chunks: both key buffers reused
-def test_batched_keygen_super_groups_against_c_oracle(swap, n, k, l, L, monkeypatch):
+@pytest.mark.parametrize("n,k,l,L", [(150, 256, 8, 2), (70, 9, 8, 3), (1100, 32, 16, 2),
+                                            (3100, 8, 8, 2),      # four 1024-party chunks: both key buffers reused
+                                            (40, 24, 8, 2),       # below 64 parties: transposed CRS as the streamed operand
+                                            (5, 12, 8, 2)])       # below 8: four per pass on the integer VALU
+def test_batched_keygen_super_groups_against_c_oracle(n, k, l, L):
     # pvw_keygen on the matrix cores (public_key.rs:111-147, crs.rs:138-171) against the C restatement, with seeded
-    # and with explicit key errors.  swap = 1 (default): parties are the GEMM rows and the CRS columns are
-    # digitised once per call (also: ragged k, more than one 1024-party chunk); swap = 0: the transposed CRS is
-    # the streamed operand and super-groups of 128 secret keys are digitised
-    monkeypatch.setenv("PVW_KEYGEN_SWAP", str(swap))
+    # and with explicit key errors.  From 64 parties up the parties are the GEMM rows and the CRS columns are
+    # digitised once per call (also: ragged k, more than one 1024-party chunk); the earlier form (transposed CRS
+    # streamed, super-groups of 128 secret keys digitised) serves 8..63 parties here and every size in
+    # tests/test_gpu_tuning.py (PVW_KEYGEN_SWAP=0)
+    batched_keygen_case(n, k, l, L)
+
+
+def batched_keygen_case(n, k, l, L):
     moduli = M.bench_moduli(L)
     p = build_params(n, k, l, moduli)
     seed = bytes([0x5A]) * 32
@@ -690,14 +756,107 @@ def test_config4_full_size_sampled_rows_against_c_oracle():
             assert np.array_equal(ct.c1, c1o), "c1"
 
 
-def test_read_bandwidth_probe_runs():
-    # the measurement aid bench.py reports beside mac_rows (same loads, no arithmetic): runs and gives a sane rate
-    import ctypes as C
-    from pvw_rs_amd import _ffi
-    p = build_params(2048, 256, 8, M.bench_moduli(17))
-    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
-    gpk.fill_uniform(SEED)
-    sec, nbytes = C.c_double(0.0), C.c_uint64(0)
-    P.api._check(_ffi.lib().pvw_selftest_read_bandwidth(p._h, 5, C.byref(sec), C.byref(nbytes)))
-    assert nbytes.value == 2048 // 16 * 17 * 256 * 1024
-    assert 500.0 < nbytes.value / sec.value / 1e9 < 8000.0
+
+def _bench_config_against_c_oracle(n):
+    """one encrypt at a BASELINE geometry (k=256, l=8, 17 limbs) in full against the C restatement, plus the
+    size-independent linearity property"""
+    from pvw_rs_amd import workloads as W
+    k, l, L = 256, 8, 17
+    moduli = W.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, W.SEED_A))
+    gpk.fill_uniform(W.SEED_B)
+    scalars = np.array(W.scalars(n), dtype=np.uint64)
+    ct = P.encrypt(scalars, gpk, W.SEED_ENC)
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(W.SEED_A, M.DOM_CRS, 0, k * k).reshape(k, k, L, l)
+    b_hat = orc.fill_uniform(W.SEED_B, M.DOM_PK, 0, n * k).reshape(n, k, L, l)
+    r = O.sample_cbd(W.SEED_ENC, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(W.SEED_ENC, M.DOM_E1, 0, k, l, 100)
+    e2 = O.sample_uniform(W.SEED_ENC, M.DOM_E2, 0, n, l, 200)
+    c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), scalars, r, e1, e2)
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+    ct5 = P.encrypt(scalars + np.uint64(5), gpk, W.SEED_ENC)          # Enc(m + 5) - Enc(m) = 5 * g-hat, limb-wise
+    g = p.gadget_polynomial(P.REPR_NTT)
+    for i, q in enumerate(moduli):
+        diff = (ct5.c2[:, i].astype(object) - ct.c2[:, i].astype(object)) % q
+        assert (diff == ((5 * g[i].astype(object)) % q)[None, :]).all()
+    assert np.array_equal(ct5.c1, ct.c1)
+
+
+def test_config1_plumbing_size_against_c_oracle():
+    # BASELINE.json configs[0]: n=16, k=256, l=8, 1037-bit q -- c1 (k^2 MACs) dominates, one row block of B
+    _bench_config_against_c_oracle(16)
+
+
+def test_config3_full_size_against_c_oracle():
+    # BASELINE.json configs[2], the headline: n=4096, k=256, l=8, 17 limbs -- every c1 and c2 polynomial
+    _bench_config_against_c_oracle(4096)
+
+
+def test_reference_128_bit_parameter_set_full_pipeline():
+    # the reference's one "128-bit" set at full size (examples/pvw_valid_dec.rs:40-52; tests/params.rs:253-274
+    # sweeps k up to 1024): n=5, k=1024, l=8, 4 x 56-bit moduli, variance 10, bounds (1, 1172385).
+    # keygen -> encrypt (one dealer: mac_rows; five dealers: the rolled digit GEMM at k=1024) -> decrypt -> decode,
+    # each stage against the C restatement / the big-integer model
+    n, k, l, moduli, variance, b1, b2 = 5, 1024, 8, EXAMPLE_MODULI, 10.0, 1, 1172385
+    L = len(moduli)
+    p = build_params(n, k, l, moduli, variance, (b1, b2))
+    assert p.verify_correctness_condition()
+    seed = bytes([0x80]) * 32
+    orc = O.Oracle(moduli, l)
+    crs = P.PvwCrs.new_deterministic(p, seed)
+    a_hat = crs.matrix(P.REPR_NTT)
+    assert np.array_equal(a_hat, orc.fill_uniform(seed, M.DOM_CRS, 0, k * k).reshape(k, k, L, l))
+    gpk = P.GlobalPublicKey.new(crs)
+    parties = [P.Party.new(i, p, seed) for i in range(n)]
+    gpk.generate_all_party_keys(parties, seed)
+    sk = O.sample_cbd(seed, M.DOM_SK, 0, n * k, l, variance).reshape(n, k, l)
+    assert np.array_equal(np.stack([pt.secret_key.secret_coeffs for pt in parties]), sk)
+    assert np.abs(sk).max() > 2                                         # variance 10: the wide CBD branch (uniform.rs:45-68)
+    ek = O.sample_uniform(seed, M.DOM_EKEY, 0, n * k, l, b1).reshape(n, k, l)
+    b_hat = gpk.matrix(repr=P.REPR_NTT)
+    assert np.array_equal(b_hat, orc.keygen(a_hat, sk, ek)), "keygen"
+    g_hat = p.gadget_polynomial(P.REPR_NTT)
+    rows = [[dealer * 100 + j for j in range(1, n + 1)] for dealer in range(n)]   # pvw_valid_dec.rs:117-124 pattern
+    cts = P.encrypt_all_party_shares(rows, gpk, seed)                   # 5 dealers -> gemm_digits, rolled K loop
+    for d in range(n):
+        sd = P.api._dealer_seed(seed, d)
+        r = O.sample_cbd(sd, M.DOM_R, 0, k, l, variance)
+        e1 = O.sample_uniform(sd, M.DOM_E1, 0, k, l, b1)
+        e2 = O.sample_uniform(sd, M.DOM_E2, 0, n, l, b2)
+        c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, np.array(rows[d], dtype=np.uint64), r, e1, e2)
+        assert np.array_equal(cts[d].c1, c1o) and np.array_equal(cts[d].c2, c2o), f"multi-dealer encrypt {d}"
+        one = P.encrypt(rows[d], gpk, sd)                               # mac_rows at k = 1024
+        assert np.array_equal(one.c1, c1o) and np.array_equal(one.c2, c2o), f"encrypt {d}"
+    mparams = M.Params(n, k, l, moduli, variance, b1, b2)
+    ok = total = 0
+    for i in range(n):
+        vals, noisy = P.api._decrypt_batch(p, cts, parties[i].secret_key, i, return_noisy=True)
+        c1s = np.stack([ct.c1 for ct in cts])
+        c2col = np.stack([ct.c2[i] for ct in cts])
+        want_noisy = orc.decrypt_noisy(sk[i], c1s, c2col)
+        assert np.array_equal(noisy, want_noisy), f"decrypt party {i}"
+        assert vals == [M.decode_scalar_pvw(rns_to_ring(want_noisy[d], moduli), mparams) for d in range(n)], f"decode {i}"
+        ok += sum(v == rows[d][i] for d, v in enumerate(vals))
+        total += n
+    assert ok >= 0.95 * total                                           # tests/crypto.rs:295-304
+
+
+def test_key_material_is_wiped_from_device_scratch():
+    # SecretKey is Zeroize + ZeroizeOnDrop in the reference (secret_key.rs:20-30): after key generation and
+    # decryption no device region that held sk coefficients, NTT(sk), key errors or their tiled / digitised copies
+    # reads anything but zero (pvw_selftest_secret_residue scans what the calls declared secret + every s-hat block)
+    for n, k in ((150, 32), (20, 24), (5, 12)):                        # swapped GEMM form, transposed-CRS form, VALU form
+        p = build_params(n, k, 8, M.bench_moduli(3))
+        gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+        parties = [P.Party.new(i, p, SEED) for i in range(n)]
+        assert P.api._secret_residue(p)[0] == 0                         # SecretKey::random staging
+        gpk.generate_all_party_keys(parties, SEED)
+        nz, scanned = P.api._secret_residue(p)
+        assert nz == 0 and scanned > n * k * 8, (n, k, nz, scanned)
+        ct = P.encrypt(list(range(n)), gpk, SEED)
+        got = P.decrypt_party_value(ct, parties[1].secret_key, 1)
+        assert got == 1
+        nz, scanned = P.api._secret_residue(p)
+        assert nz == 0 and scanned > 0, (n, k, nz)

@@ -1,0 +1,111 @@
+"""GPU tests of the MEASUREMENT build libpvw_hip_tuning.so (-DPVW_TUNING=1, include/pvw_hip_tuning.h): every
+kernel schedule / launch shape / decode form that the environment selectors reach computes what the oracle
+computes, and the timing switches exist there -- and only there.  The shipped library picks its schedules by
+shape and reads no environment variable (tests/test_gpu_parity.py runs on it)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pvw_model as M
+import pvw_rs_amd as P
+from pvw_rs_amd import _ffi
+from _util import SEED, TEST_MODULI, primes_1mod
+import test_gpu_parity as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def tuning_library():
+    """contexts created inside these tests live in libpvw_hip_tuning.so (a context keeps its library for life)"""
+    prev = _ffi.select("tuning")
+    yield
+    _ffi.select(prev)
+
+
+def test_tuning_build_is_selected():
+    p = T.build_params(3, 4, 8, TEST_MODULI)
+    assert p._lib.pvw_build_is_tuning() == 1 and _ffi._load("default").pvw_build_is_tuning() == 0
+
+
+@pytest.mark.parametrize("n,k,l,L", T.MAC_SCHEDULE_CASES)
+def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
+    # every streaming schedule of mac_rows (PVW_MAC_VARIANT) computes the same c1, c2 (encryption.rs:158,177-200)
+    run, c1o, c2o = T.mac_rows_case(n, k, l, L)
+    for variant in range(0, 24):
+        monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
+        ct = run()
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
+
+
+@pytest.mark.parametrize("k,l,L,D", T.DECRYPT_SHAPE_CASES)
+def test_decrypt_mac_launch_shapes_agree_with_c_oracle(k, l, L, D, monkeypatch):
+    # every launch shape of decrypt_party_value's <sk, c1> (decryption.rs:257-274) gives the oracle's noisy
+    # polynomials: the shape-selected default, the dealer-grouped form and the full-width form, each with 1, 2, 3
+    # j-replicas
+    run, want = T.decrypt_mac_case(k, l, L, D)
+    for variant, c in [(0, 0), (10, 0), (10, 2), (10, 3), (11, 0), (60, 0), (60, 1), (60, 2), (61, 3), (62, 0), (64, 0)]:
+        monkeypatch.setenv("PVW_DEC_VARIANT", str(variant))
+        monkeypatch.setenv("PVW_DEC_C", str(c))
+        assert np.array_equal(run(), want), (variant, c)
+
+
+@pytest.mark.parametrize("D", [1, 2, 4, 7])
+def test_multi_dealer_encrypt_on_the_integer_valu(D, monkeypatch):
+    # PVW_GEMM_MIN_DEALERS=0: mac_rows_multi (up to four dealers per pass over B-hat) at every dealer count
+    monkeypatch.setenv("PVW_GEMM_MIN_DEALERS", "0")
+    T.multi_dealer_case(D)
+
+
+@pytest.mark.parametrize("l,moduli", [(8, TEST_MODULI), (8, M.bench_moduli(17)), (16, M.bench_moduli(34)), (64, primes_1mod(128, 5))])
+def test_device_decode_forms_match_model(l, moduli, monkeypatch):
+    # decode_scalar_pvw_rns (decryption.rs:10-58): lifted chain with 4 / 2 / 8 waves per ciphertext, one wave per
+    # ciphertext with an RNS round trip per step, one thread per ciphertext
+    T.device_decode_case(l, moduli, lambda v: monkeypatch.setenv("PVW_DECODE_VARIANT", str(v)), (0, 3, 4, 2, 1))
+
+
+@pytest.mark.parametrize("n,k,l,L", [(150, 256, 8, 2), (70, 9, 8, 3)])
+def test_batched_keygen_transposed_crs_form(n, k, l, L, monkeypatch):
+    # PVW_KEYGEN_SWAP=0: the transposed CRS is the streamed operand and super-groups of secret keys are digitised
+    monkeypatch.setenv("PVW_KEYGEN_SWAP", "0")
+    T.batched_keygen_case(n, k, l, L)
+
+
+def test_read_bandwidth_probe_runs():
+    # the measurement aid bench.py reports beside mac_rows (same loads, no arithmetic): runs and gives a sane rate
+    p = T.build_params(2048, 256, 8, M.bench_moduli(17))
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    sec, nbytes = C.c_double(0.0), C.c_uint64(0)
+    p._call("pvw_selftest_read_bandwidth", 5, C.byref(sec), C.byref(nbytes))
+    assert nbytes.value == 2048 // 16 * 17 * 256 * 1024
+    assert 500.0 < nbytes.value / sec.value / 1e9 < 8000.0
+
+
+def _encrypt_once(lib_name):
+    prev = _ffi.select(lib_name)
+    try:
+        p = T.build_params(40, 16, 8, M.bench_moduli(3))
+        gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+        gpk.fill_uniform(SEED)
+    finally:
+        _ffi.select(prev)
+    ct = P.encrypt([(i * 1000 + 1) % (1 << 32) for i in range(40)], gpk, SEED)
+    return ct.c1.copy(), ct.c2.copy()
+
+
+def test_prologue_debug_switch_exists_only_in_the_tuning_build(monkeypatch):
+    # PVW_PROLOGUE_DEBUG=1 makes the TUNING build skip sampling (a timing ablation: ciphertexts without
+    # randomness); the shipped library has neither the lookup nor the branch, so the variable cannot touch it
+    # (the reference samples unconditionally, encryption.rs:135-167)
+    want = _encrypt_once("default")
+    assert all(np.array_equal(a, b) for a, b in zip(_encrypt_once("tuning"), want))
+    monkeypatch.setenv("PVW_PROLOGUE_DEBUG", "1")
+    monkeypatch.setenv("PVW_GEMM_DEBUG", "3")
+    monkeypatch.setenv("PVW_DECODE_TIMING", "1")
+    monkeypatch.setenv("PVW_MAC_VARIANT", "7")
+    got = _encrypt_once("default")
+    assert all(np.array_equal(a, b) for a, b in zip(got, want)), "the shipped library reacted to a debug variable"
+    got_t = _encrypt_once("tuning")
+    assert not np.array_equal(got_t[1], want[1]), "the tuning build should have skipped sampling"

@@ -27,6 +27,85 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_ffi._SIGNATURES), "ctypes table and header disagree"
 
 
+def test_tuning_library_is_a_superset_and_the_shipped_one_has_no_switches():
+    # the measurement build exports everything the shipped one does plus include/pvw_hip_tuning.h; the shipped
+    # library imports no getenv and carries none of the switch names: no environment variable can make it skip
+    # sampling (the reference samples unconditionally, encryption.rs:135-167)
+    import subprocess
+    tuning_h = open(os.path.join(ROOT, "include", "pvw_hip_tuning.h")).read()
+    extra = re.findall(r"^PVW_API int32_t (pvw_\w+)\(", tuning_h, flags=re.M)
+    assert extra == ["pvw_selftest_read_bandwidth"] and set(extra) == set(_ffi._TUNING_SIGNATURES)
+    dflt, tun = _ffi._load("default"), _ffi.tuning_lib()
+    assert dflt.pvw_build_is_tuning() == 0 and tun.pvw_build_is_tuning() == 1
+    for name in extra:
+        assert hasattr(tun, name) and not hasattr(dflt, name)
+    for name in _ffi._SIGNATURES:
+        assert hasattr(tun, name)
+    def strings(path):
+        return subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout
+    def undefined(path):
+        return subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    switches = ("PVW_PROLOGUE_DEBUG", "PVW_GEMM_DEBUG", "PVW_DECODE_TIMING", "PVW_MAC_VARIANT", "PVW_DEC_VARIANT",
+                "PVW_GEMM_MIN_DEALERS", "PVW_KEYGEN_SWAP")
+    s_def, s_tun = strings(_ffi.LIB_PATH), strings(_ffi.LIB_TUNING_PATH)
+    for name in switches:
+        assert name not in s_def, f"the shipped library mentions {name}"
+        assert name in s_tun
+    assert "getenv" not in undefined(_ffi.LIB_PATH)
+    assert "getenv" in undefined(_ffi.LIB_TUNING_PATH)
+
+
+def test_workload_definition_agrees_with_the_checker():
+    # bench.py's workload lives in the product (pvw_rs_amd/workloads.py); the oracle keeps its own copy of the rule
+    from pvw_rs_amd import workloads as W
+    assert W.bench_moduli(34) == M.bench_moduli(34) and W.bench_moduli(36) == M.bench_moduli(36)
+    assert all(q % 64 == 1 and q < 1 << 61 for q in W.bench_moduli(34))
+    assert (_ffi.DOM_R, _ffi.DOM_E1, _ffi.DOM_E2, _ffi.DOM_SK, _ffi.DOM_EKEY, _ffi.DOM_CRS, _ffi.DOM_GAUSS, _ffi.DOM_PK) == \
+        (M.DOM_R, M.DOM_E1, M.DOM_E2, M.DOM_SK, M.DOM_EKEY, M.DOM_CRS, M.DOM_GAUSS, M.DOM_PK)
+    assert W.ENCRYPT_CONFIGS["c3"][:4] == (4096, 256, 8, 17) and W.DECRYPT_CONFIGS["c5shard"][:4] == (1024, 512, 16, 34)
+
+
+def test_crs_seed_from_tag_is_siphash13_of_tag_crs():
+    # PvwCrs::new_from_tag (crs.rs:74-90): DefaultHasher = SipHash-1-3 with a zero key over tag + "CRS" + 0xFF.
+    # The hash is pinned by the published SipHash-2-4 vector through the same code (round counts are parameters).
+    import ctypes as C
+    lib = _ffi.lib()
+    msg = bytes(range(15))
+    out = C.c_uint64()
+    assert lib.pvw_selftest_siphash(msg, len(msg), 0x0706050403020100, 0x0F0E0D0C0B0A0908, 2, 4, C.byref(out)) == 0
+    assert out.value == 0xA129CA6149BE45E5                        # SipHash paper, appendix A
+    seed = P.PvwCrs.seed_from_tag("pvss-session-1")
+    assert len(seed) == 32 and seed[:8] == seed[8:16] == seed[16:24] == seed[24:]
+    m = b"pvss-session-1" + b"CRS" + b"\xff"
+    assert lib.pvw_selftest_siphash(m, len(m), 0, 0, 1, 3, C.byref(out)) == 0
+    assert seed[:8] == out.value.to_bytes(8, "little")
+    assert P.PvwCrs.seed_from_tag("other") != seed
+
+
+def test_secret_key_zeroize_on_drop():
+    # secret_key.rs:20-30 / tests/keys.rs:515-538: the mirror owns its coefficients and clears them
+    p = _builder().build()
+    src = np.arange(4 * 8, dtype=np.int64).reshape(4, 8) - 7
+    key = P.SecretKey.from_coefficients(p, src)
+    view = key.secret_coeffs
+    key.zeroize()
+    assert not view.any() and src.any()                           # the caller's array is not the key's storage
+
+
+def test_bench_self_launches_its_ranks():
+    # `python bench.py --gpus 2` must start torch.distributed.run itself (as a child, before any GPU call);
+    # on a box without a GPU both ranks then stop at the device check -- not at "must be launched with ..."
+    import subprocess
+    import sys
+    if P.device_available():
+        pytest.skip("GPU present: covered by tests/test_dist_gloo.py::test_bench_two_ranks_on_one_gpu")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a gfx950 GPU") >= 1, r.stderr[-2000:]
+    assert "must be launched with" not in r.stderr
+
+
 def test_error_codes_follow_pvw_error_order():
     header = open(os.path.join(ROOT, "include", "pvw_hip.h")).read()
     codes = dict((int(v), k) for k, v in re.findall(r"(PVW_ERR_\w+) = (\d+)", header))

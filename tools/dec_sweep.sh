@@ -1,4 +1,6 @@
 #!/bin/bash
+# the schedule selectors exist in the measurement build only (include/pvw_hip_tuning.h)
+export PVW_HIP_LIBRARY=tuning
 # sweep of decrypt_mac launch shapes: PVW_DEC_VARIANT x PVW_DEC_C on two decrypt workloads
 out=gpurun_out/dec_sweep.log; : > $out
 run() {

@@ -3,8 +3,9 @@
 import os, sys
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
-import pvw_model as M
+sys.path[:0] = [ROOT]
+os.environ["PVW_HIP_LIBRARY"] = "tuning"      # PVW_DECODE_TIMING exists in the measurement build only
+from pvw_rs_amd import workloads as M
 import pvw_rs_amd as P
 
 L, l, count = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

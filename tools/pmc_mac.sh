@@ -4,7 +4,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_mac && mkdir -p $R/gpurun_out/pmc_mac
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $R/gpurun_out/pmc_mac/p1 -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu "$@" > $R/gpurun_out/pmc_mac/p1.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $R/gpurun_out/pmc_mac/p1 -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --sustain-seconds 0 --no-probe "$@" > $R/gpurun_out/pmc_mac/p1.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob, collections

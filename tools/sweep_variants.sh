@@ -1,4 +1,6 @@
 #!/bin/bash
+# the schedule selectors exist in the measurement build only (include/pvw_hip_tuning.h)
+export PVW_HIP_LIBRARY=tuning
 # A/B the streaming-schedule variants of mac_rows on the GPU box (tuning aid).
 # usage: [MACV="0 3 9 10"] [CFGS="c3 c2 c4shard"] [REPS=2] tools/sweep_variants.sh <outfile>
 out=${1:-gpurun_out/sweep.txt}
