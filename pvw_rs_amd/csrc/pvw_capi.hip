@@ -117,6 +117,7 @@ struct Workspace {
   bool own_stream = false;
   u64* rhat = nullptr;       // [L][k][l]  (x4: up to four r-hat / s-hat vectors)
   size_t rhat_bytes = 0;
+  u32* counters = nullptr;   // work-queue words of the persistent mac_rows (zeroed once; the kernel re-arms them)
   u64* scalars = nullptr;    // [n]
   u64* c1 = nullptr;         // [rowsA][L][l]
   u64* c2 = nullptr;         // [rowsB][L][l]
@@ -406,6 +407,9 @@ static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
   const size_t k = c->k, P = c->poly();
   PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
   w->rhat_bytes = 4 * k * P * 8;
+  PVW_HIP(hipMemset(w->rhat, 0, w->rhat_bytes));          // recycled device memory may hold an earlier owner's data
+  PVW_HIP(hipMalloc((void**)&w->counters, 256));
+  PVW_HIP(hipMemset(w->counters, 0, 256));
   return PVW_OK;
 }
 static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
@@ -433,6 +437,7 @@ static void ws_free(Workspace* w) {
   if (w->rhat && w->rhat_bytes) hipMemset(w->rhat, 0, w->rhat_bytes);
   if (w->scratch) hipMemset(w->scratch, 0, w->scratch_bytes);
   hipFree(w->rhat);
+  hipFree(w->counters);
   hipFree(w->scalars);
   hipFree(w->c1);
   hipFree(w->c2);
@@ -1260,7 +1265,7 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
   {
     ProfScope ps(c, "mac_rows", s);
     MacSection a{c->dA, d_c1, d_c1, rA, 0}, b{c->dB, d_c2, d_c2, rB, 0};
-    PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s));                      // crs.rs:188-201, encryption.rs:177-200
+    PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s, w->counters));         // crs.rs:188-201, encryption.rs:177-200
   }
   if (out_repr == PVW_REPR_POWER) {
     ProfScope ps(c, "intt", s);

@@ -66,9 +66,11 @@ struct MacSection {
   u32 nrows;
   u32 row_blocks;
 };
-// c1 (section a: A-hat rows) and c2 (section b: B-hat rows) in a single launch
+// c1 (section a: A-hat rows) and c2 (section b: B-hat rows) in a single launch.  `counters`: two zeroed u32 words
+// owned by the calling stream's workspace (work queue of the persistent form; the kernel re-arms them itself);
+// NULL selects the one-workgroup-per-item form.
 hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat,
-                           const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s);
+                           const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s, u32* counters = nullptr);
 // group != 0: polynomial p goes to out + (p / group) * stride_group + (p % group) * stride_poly
 hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t stride_poly,
                        size_t stride_limb, u32 count, bool do_ntt, const DevTables& t, u32 L,

@@ -32,8 +32,10 @@ typedef u64 v2u64 __attribute__((ext_vector_type(2)));  // one 16-byte lane acce
 // grid = row_blocks * L workgroups of 256 threads; the 4 waves split the j range, each
 // streaming a contiguous run of 1-KiB tiles; r-hat slices are staged in wave-private LDS.
 // ------------------------------------------------------------------------------------
-template <int ELL, int U, bool NT, bool DBUF, bool ILV = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSection sb,
+// WPE: minimum waves per SIMD the register allocation must leave room for (1 = unconstrained).  ARITH (tuning build,
+// timing experiments only, wrong results): 2 = the modular MAC, 1 = one of the two MACs per 16 bytes, 0 = an xor.
+template <int ELL, int U, bool NT, bool DBUF, bool ILV = false, int NW = 4, int WPE = 1, int ARITH = 2>
+__global__ __launch_bounds__(NW * 64, WPE) void mac_rows_kernel(MacSection sa, MacSection sb,
                                                         const u64* __restrict__ rhat,
                                                         const Mod* __restrict__ mods, u32 k, u32 L) {
   constexpr int HALF = ELL / 2;   // 16-byte slot pairs per polynomial limb
@@ -75,6 +77,18 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
   Acc a0, a1;
   acc_zero(a0);
   acc_zero(a1);
+  auto mac2 = [&](const v2u64& xv, const v2u64& yv) {
+    if constexpr (ARITH == 2) {
+      acc_mac_dev(a0, xv.x, yv.x);
+      acc_mac_dev(a1, xv.y, yv.y);
+    } else if constexpr (ARITH == 1) {
+      acc_mac_dev(a0, xv.x, yv.x);
+      a1.ll ^= xv.y ^ yv.y;
+    } else {
+      a0.ll ^= xv.x ^ yv.x;
+      a1.ll ^= xv.y ^ yv.y;
+    }
+  };
 
   for (u32 jc = j0; jc < j1; jc += JC) {
     const u32 cnt = (j1 - jc) < (u32)JC ? (j1 - jc) : (u32)JC;
@@ -122,8 +136,7 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             v2u64 y = lw[(jj + u) * HALF + sp];
-            acc_mac_dev(a0, x[u].x, y.x);
-            acc_mac_dev(a1, x[u].y, y.y);
+            mac2(x[u], y);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) x[u] = xn[u];
@@ -131,8 +144,7 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           v2u64 y = lw[(jj + u) * HALF + sp];
-          acc_mac_dev(a0, x[u].x, y.x);
-          acc_mac_dev(a1, x[u].y, y.y);
+          mac2(x[u], y);
         }
         jj += U;
       }
@@ -144,16 +156,14 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           v2u64 y = lw[(jj + u) * HALF + sp];
-          acc_mac_dev(a0, x[u].x, y.x);
-          acc_mac_dev(a1, x[u].y, y.y);
+          mac2(x[u], y);
         }
       }
     }
     for (; jj < cnt; ++jj) {
       v2u64 xv = ld(jj);
       v2u64 y = lw[jj * HALF + sp];
-      acc_mac_dev(a0, xv.x, y.x);
-      acc_mac_dev(a1, xv.y, y.y);
+      mac2(xv, y);
     }
   }
 
@@ -180,6 +190,192 @@ __global__ __launch_bounds__(NW * 64) void mac_rows_kernel(MacSection sa, MacSec
       }
       reinterpret_cast<v2u64*>(out)[out_o] = s;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// mac_rows, persistent form.  The grid is sized to what the chip holds at once (workgroups per CU x CUs) and every
+// workgroup walks work items (row block, limb) handed out by a device-side counter, so a slot never idles between
+// two items while the dispatcher tears one workgroup down and sets the next one up, and the last item's
+// epilogue (Barrett, cross-wave sum, addend, store) runs UNDER the first tile loads of the next item:
+//   * item i+1 is known while item i streams (the counter is popped one item ahead), so the last tile group of
+//     item i prefetches the first group and the r-hat slice of item i+1 instead of nothing;
+//   * partial sums alternate between two small LDS buffers, so one workgroup barrier per item is enough.
+// Same tiling, same lazy accumulation, same per-item arithmetic as mac_rows_kernel -- bit-identical results.
+// counters[0] = next item to hand out (every item, the first one of a workgroup included, comes from it: a
+// workgroup that becomes resident late simply takes what is left), counters[1] = workgroups that have finished;
+// the last one to finish re-arms both for the next launch on this stream (per-workspace counters: stream order
+// makes that safe).  Every workgroup terminates after at most items + 2 pops, whatever the dispatch order.
+// Needs k % (NW * U) == 0 and (k / NW) % JC == 0 or k / NW < JC handled by the launcher (else mac_rows_kernel).
+// ------------------------------------------------------------------------------------
+template <int ELL, int U, int WPE, int NW = 4>
+__global__ __launch_bounds__(NW * 64, WPE) void mac_rows_persist_kernel(MacSection sa, MacSection sb,
+                                                                const u64* __restrict__ rhat,
+                                                                const Mod* __restrict__ mods, u32 k, u32 L,
+                                                                u32 items, u32* __restrict__ counters) {
+  constexpr int HALF = ELL / 2;
+  constexpr int R = 128 / ELL;
+  constexpr int JC = 256 / HALF;                 // tiles per r-hat chunk: 4 KiB slabs (64 at l = 8, 32 at l = 16, ...)
+  constexpr int RN = JC * HALF / 64;             // = 4 sixteen-byte r-hat elements per lane per chunk
+  constexpr int GPC = JC / U;                    // tile groups per chunk
+  static_assert(JC % U == 0 && GPC >= 1 && (GPC % 2 == 0 || GPC == 1), "groups are processed in pairs");
+  __shared__ v2u64 slab[NW][JC * HALF];          // wave-private r-hat slices (a wave's LDS operations execute in order,
+                                                 // so the next chunk's slice can overwrite the slab once the last
+                                                 // multiply of the current chunk has been issued)
+  __shared__ v2u64 part[2][NW * 64];             // wave partials, two generations
+  __shared__ u32 nextslot[2];
+
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 sp = lane % HALF, rho = lane / HALF;
+  const u32 T = k / NW;                          // tiles per wave per item
+  const u32 NC = T / JC;                         // whole chunks per item (launcher guarantees T % JC == 0)
+
+  struct Item {           // everything here is wave-uniform (scalar registers)
+    const v2u64* mp;      // the wave's first tile of the item
+    const v2u64* rp;      // r-hat of the item's limb
+    u32 limb, rb;
+    bool in_a;
+  };
+  auto setup = [&](u32 it) -> Item {
+    Item x;
+    x.limb = it % L;
+    const u32 rbg = it / L;
+    x.in_a = rbg < sa.row_blocks;
+    x.rb = x.in_a ? rbg : rbg - sa.row_blocks;
+    const u64* M = x.in_a ? sa.M : sb.M;
+    x.mp = reinterpret_cast<const v2u64*>(M + ((size_t)x.rb * L + x.limb) * (size_t)k * 128) + (size_t)wave * U * 64;
+    x.rp = reinterpret_cast<const v2u64*>(rhat + (size_t)x.limb * k * ELL);
+    return x;
+  };
+  // local tile t of this wave is global tile (t / U) * NW * U + wave * U + t % U (the waves interleave groups of U)
+  auto ld_group = [&](const Item& it, u32 g, v2u64 (&dst)[U]) {
+    const v2u64* p = it.mp + (size_t)g * (NW * U * 64);     // scalar base; the lane offset is the only vector part
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[u] = __builtin_nontemporal_load(p + u * 64 + lane);
+  };
+  // this lane's RN r-hat elements of a chunk: element idx = lane + 64 x of the chunk, i.e. slot pair idx % HALF of
+  // local tile chunk * JC + idx / HALF
+  u32 roff[RN];
+#pragma unroll
+  for (int x = 0; x < RN; ++x) {
+    const u32 idx = lane + 64 * x, t = idx / HALF;            // t < JC: position inside a chunk
+    roff[x] = ((t / U) * (NW * U) + wave * U + t % U) * HALF + idx % HALF;
+  }
+  auto fetch_r = [&](const Item& it, u32 chunk, v2u64 (&rv)[RN]) {
+    const v2u64* p = it.rp + (size_t)chunk * (JC / U) * (NW * U) * HALF;   // whole groups per chunk (JC % U == 0)
+#pragma unroll
+    for (int x = 0; x < RN; ++x) rv[x] = p[roff[x]];
+  };
+
+  // the first two items in one pop; from then on the pop for item i+2 flies while item i streams
+  if (threadIdx.x == 0) nextslot[0] = atomicAdd(&counters[0], 2u);
+  __syncthreads();
+  u32 cur = __builtin_amdgcn_readfirstlane(nextslot[0]);   // item numbers are workgroup-uniform: keep them (and every
+                                                           // pointer derived from them) in scalar registers
+  if (cur >= items) {                            // nothing left: sign off
+    if (threadIdx.x == 0) {
+      const u32 done = atomicAdd(&counters[1], 1u);
+      if (done == gridDim.x - 1) { counters[0] = 0; counters[1] = 0; }
+    }
+    return;
+  }
+  u32 nxt = cur + 1;
+  u32 gen = 0;                                   // item generation: partial buffer / nextslot parity
+
+  Item ic = setup(cur);
+  v2u64 xa[U], xb[U], rv[RN];
+  fetch_r(ic, 0, rv);
+  ld_group(ic, 0, xa);
+
+  for (;;) {
+    u32 nn = 0;
+    if (threadIdx.x == 0) nn = atomicAdd(&counters[0], 1u);              // successor of nxt, needed at the barrier below
+    const bool have_next = nxt < items;          // workgroup-uniform
+    Item in = ic;
+    if (have_next) in = setup(nxt);
+    Acc a0, a1;
+    acc_zero(a0);
+    acc_zero(a1);
+    for (u32 c = 0; c < NC; ++c) {
+      v2u64* lw = slab[wave];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int x = 0; x < RN; ++x) lw[lane + 64 * x] = rv[x];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const bool last_chunk = c + 1 == NC;
+      // one group: prefetch what comes next into `nx`, multiply `cx` against the slab
+      auto group = [&](u32 g, v2u64 (&cx)[U], v2u64 (&nx)[U]) {
+        const bool last_in_chunk = g + 1 == (u32)GPC;
+        if (!last_in_chunk) {
+          ld_group(ic, c * GPC + g + 1, nx);
+        } else if (!last_chunk) {
+          fetch_r(ic, c + 1, rv);
+          ld_group(ic, (c + 1) * GPC, nx);
+        } else if (have_next) {
+          fetch_r(in, 0, rv);
+          ld_group(in, 0, nx);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const v2u64 y = lw[(g * U + u) * HALF + sp];
+          acc_mac_dev(a0, cx[u].x, y.x);
+          acc_mac_dev(a1, cx[u].y, y.y);
+        }
+      };
+      if constexpr (GPC == 1) {
+        group(0, xa, xb);
+#pragma unroll
+        for (int u = 0; u < U; ++u) xa[u] = xb[u];
+      } else {
+#pragma unroll
+        for (int g = 0; g < GPC; g += 2) {
+          group(g, xa, xb);
+          group(g + 1, xb, xa);
+        }
+      }
+    }
+    // epilogue of item `cur` (its successor's first loads are in flight): one Barrett per wave partial, cross-wave
+    // sum through LDS, addend, store
+    const Mod m = mods[ic.limb];
+    v2u64 pt;
+    pt.x = acc_reduce(a0, m);
+    pt.y = acc_reduce(a1, m);
+    part[gen][wave * 64 + lane] = pt;
+    if (threadIdx.x == 0) nextslot[gen ^ 1] = nn;
+    __syncthreads();
+    const u32 nn_all = __builtin_amdgcn_readfirstlane(nextslot[gen ^ 1]);
+    if (wave == 0) {
+      const u32 nrows = ic.in_a ? sa.nrows : sb.nrows;
+      const u64* addend = ic.in_a ? sa.addend : sb.addend;
+      u64* out = ic.in_a ? sa.out : sb.out;
+      const u32 out_row = ic.rb * R + rho;
+      if (out_row < nrows) {
+        v2u64 s = pt;
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          const v2u64 t = part[gen][w * 64 + lane];
+          s.x = addmod(s.x, t.x, m.q);
+          s.y = addmod(s.y, t.y, m.q);
+        }
+        const size_t o = (((size_t)out_row * L + ic.limb) * ELL) / 2 + sp;
+        if (addend) {
+          const v2u64 e = reinterpret_cast<const v2u64*>(addend)[o];
+          s.x = addmod(s.x, e.x, m.q);
+          s.y = addmod(s.y, e.y, m.q);
+        }
+        reinterpret_cast<v2u64*>(out)[o] = s;
+      }
+    }
+    gen ^= 1;
+    if (!have_next) break;
+    cur = nxt;
+    nxt = nn_all;
+    ic = in;
+  }
+  if (threadIdx.x == 0) {
+    const u32 done = atomicAdd(&counters[1], 1u);
+    if (done == gridDim.x - 1) { counters[0] = 0; counters[1] = 0; }
   }
 }
 
@@ -2099,12 +2295,43 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const u64* __restrict__
 static int mac_variant() {   // read per launch: the parity tests walk the variants in one process
   return (int)PVW_ENV_INT("PVW_MAC_VARIANT", 0);
 }
+// persistent form: grid = what the chip holds at once (occupancy query x CUs, capped by the item count)
+template <int E, int U, int WPE>
+static bool launch_mac_persist(dim3 grid, hipStream_t s, const MacSection& sa, const MacSection& sb, const u64* rhat,
+                               const Mod* mods, u32 k, u32 L, u32* counters) {
+  constexpr int HALF = E / 2, JC = 256 / HALF;
+  if constexpr (JC % U != 0 || ((JC / U) % 2 != 0 && JC / U != 1)) return false;
+  else {
+    if (!counters || k % (4 * U) != 0 || (k / 4) % JC != 0) return false;
+    static const int resident = [] {
+      int dev = 0, cus = 0, per_cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess) return 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mac_rows_persist_kernel<E, U, WPE>, 256, 0) != hipSuccess) return 0;
+      return cus * per_cu;
+    }();
+    if (resident <= 0) return false;
+    const u32 items = grid.x;
+    const u32 wgs = items < (u32)resident ? items : (u32)resident;
+    mac_rows_persist_kernel<E, U, WPE><<<dim3(wgs), dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L, items, counters);
+    return true;
+  }
+}
+
 template <int E>
 static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacSection& sa, const MacSection& sb,
-                               const u64* rhat, const Mod* mods, u32 k, u32 L) {
+                               const u64* rhat, const Mod* mods, u32 k, u32 L, u32* counters) {
 #if PVW_TUNING
   if constexpr (E <= 16) {
     switch (variant) {
+      case 20: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 4><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 21: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // timing only
+      case 22: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 1><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // timing only
+      case 23: if (k % 32 == 0) { mac_rows_kernel<E, 8, true, true, true, 4, 4><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 30: if (launch_mac_persist<E, 16, 2>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
+      case 31: if (launch_mac_persist<E, 8, 4>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
+      case 32: if (launch_mac_persist<E, 8, 3>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
+      case 33: if (launch_mac_persist<E, 16, 3>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
       case 1: mac_rows_kernel<E, 8, false, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       case 2: mac_rows_kernel<E, 4, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       case 3: mac_rows_kernel<E, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
@@ -2146,14 +2373,14 @@ static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacS
 }
 
 hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat,
-                           const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s) {
+                           const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s, u32* counters) {
   const u32 R = 128 / ell;
   MacSection sa = a, sb = b;
   sa.row_blocks = (sa.nrows + R - 1) / R;
   sb.row_blocks = (sb.nrows + R - 1) / R;
   const u32 blocks = (sa.row_blocks + sb.row_blocks) * L;
   if (blocks == 0) return hipSuccess;
-  PVW_DISPATCH_ELL(ell, launch_mac_variant<E>(mac_variant(), dim3(blocks), s, sa, sb, rhat, t.mods, k, L));
+  PVW_DISPATCH_ELL(ell, launch_mac_variant<E>(mac_variant(), dim3(blocks), s, sa, sb, rhat, t.mods, k, L, counters));
   return hipGetLastError();
 }
 

@@ -1,0 +1,145 @@
+"""The Rust side of the boundary (rust/, source only: no Rust toolchain exists in the image, nothing there is
+compiled) is kept in step with include/pvw_hip.h mechanically: same exported symbols, same arity, same integer /
+pointer widths and constness, same #[repr(C)] field order, same status codes, and a check() that maps all 19
+codes onto the reference's PvwError variants (src/errors.rs:13-70)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "pvw_hip.h")).read()
+SYS = open(os.path.join(ROOT, "rust", "pvw-hip-sys", "src", "lib.rs")).read()
+SUPPORT = open(os.path.join(ROOT, "rust", "pvw", "src", "ffi_support.rs")).read()
+
+C_TO_RUST = {
+    "char*": "*mut c_char", "const char*": "*const c_char", "size_t": "usize", "size_t*": "*mut usize",
+    "uint8_t*": "*mut u8", "const uint8_t*": "*const u8", "int8_t*": "*mut i8", "const int8_t*": "*const i8",
+    "uint32_t": "u32", "uint32_t*": "*mut u32", "int32_t": "i32", "int32_t*": "*mut i32",
+    "uint64_t": "u64", "uint64_t*": "*mut u64", "const uint64_t*": "*const u64",
+    "int64_t": "i64", "int64_t*": "*mut i64", "const int64_t*": "*const i64",
+    "float": "f32", "double*": "*mut f64", "void*": "*mut c_void",
+    "pvw_ctx*": "*mut PvwCtx", "const pvw_ctx*": "*const PvwCtx", "pvw_ctx**": "*mut *mut PvwCtx",
+    "const pvw_params_t*": "*const PvwParamsT", "const pvw_randomness_t*": "*const PvwRandomnessT",
+}
+
+
+def _strip_comments(text):
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def c_declarations():
+    out = {}
+    for name, args in re.findall(r"PVW_API\s+int32_t\s+(pvw_\w+)\s*\((.*?)\)\s*;", _strip_comments(HEADER), flags=re.S):
+        args = " ".join(args.split())
+        types = []
+        if args not in ("void", ""):
+            for a in args.split(","):
+                m = re.match(r"(.*?)(\w+)(\[\d*\])?$", a.strip())
+                ctype = m.group(1).strip().replace(" *", "*") + ("*" if m.group(3) else "")
+                types.append((" ".join(ctype.split()), m.group(2)))
+        out[name] = types
+    return out
+
+
+def rust_declarations():
+    block = re.search(r'extern "C" \{(.*?)\n\}', SYS, flags=re.S).group(1)
+    block = re.sub(r"//.*", "", block)
+    out = {}
+    for name, args, ret in re.findall(r"pub fn (pvw_\w+)\((.*?)\)\s*->\s*(\w+);", block, flags=re.S):
+        assert ret == "i32", name
+        types = []
+        for a in filter(None, (x.strip() for x in args.split(","))):
+            an, at = a.split(":", 1)
+            types.append((" ".join(at.split()), an.strip()))
+        out[name] = types
+    return out
+
+
+def test_extern_block_matches_the_header_symbol_for_symbol():
+    c, r = c_declarations(), rust_declarations()
+    assert len(c) >= 52
+    assert set(c) == set(r), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    for name, cargs in c.items():
+        rargs = r[name]
+        assert len(cargs) == len(rargs), f"{name}: arity {len(cargs)} vs {len(rargs)}"
+        for (ct, cn), (rt, rn) in zip(cargs, rargs):
+            assert C_TO_RUST[ct] == rt, f"{name}({cn}): {ct} should be {C_TO_RUST[ct]}, the binding says {rt}"
+            assert cn == rn, f"{name}: argument {cn} is called {rn} in the binding"
+
+
+def _c_struct_fields(name):
+    body = re.search(r"typedef struct \{([^}]*)\}\s*" + name + r"\s*;", _strip_comments(HEADER)).group(1)
+    fields = []
+    for decl in filter(None, (d.strip() for d in body.split(";"))):
+        m = re.match(r"(.*?)((?:\w+(?:\[\d+\])?\s*,\s*)*\w+(?:\[\d+\])?)$", " ".join(decl.split()))
+        ctype = m.group(1).strip().replace(" *", "*")
+        for f in m.group(2).split(","):
+            f = f.strip()
+            arr = re.match(r"(\w+)\[(\d+)\]", f)
+            fields.append((arr.group(1), f"{ctype}[{arr.group(2)}]") if arr else (f, ctype))
+    return fields
+
+
+def _rust_struct_fields(name):
+    body = re.search(r"#\[repr\(C\)\][^{]*pub struct " + name + r"\s*\{(.*?)\n\}", SYS, flags=re.S).group(1)
+    return [(n, " ".join(t.split())) for n, t in re.findall(r"pub (\w+):\s*([^,\n]+),", body)]
+
+
+def test_repr_c_structs_have_the_header_field_order_and_widths():
+    widths = dict(C_TO_RUST, **{"uint8_t[32]": "[u8; 32]"})
+    for cname, rname in (("pvw_params_t", "PvwParamsT"), ("pvw_randomness_t", "PvwRandomnessT")):
+        cf, rf = _c_struct_fields(cname), _rust_struct_fields(rname)
+        assert [n for n, _ in cf] == [n for n, _ in rf], (cname, cf, rf)
+        for (n, ct), (_, rt) in zip(cf, rf):
+            assert widths[ct] == rt, f"{cname}.{n}: {ct} vs {rt}"
+
+
+def test_status_codes_and_constants_agree():
+    c_codes = dict((k, int(v)) for k, v in re.findall(r"(PVW_(?:OK|ERR_\w+)) = (\d+)", HEADER))
+    r_codes = dict((k, int(v)) for k, v in re.findall(r"pub const (PVW_(?:OK|ERR_\w+)): i32 = (\d+);", SYS))
+    assert c_codes == r_codes and len(c_codes) == 20
+    for group in (r"PVW_REPR_\w+", r"PVW_RND_\w+", r"PVW_DOM_\w+"):
+        c = dict((k, int(v)) for k, v in re.findall(r"(" + group + r") = (\d+)", HEADER))
+        r = dict((k, int(v)) for k, v in re.findall(r"pub const (" + group + r"): u32 = (\d+);", SYS))
+        assert c == r and c, group
+
+
+def test_check_maps_all_nineteen_codes_onto_pvw_error_variants():
+    # variant i (declaration order, errors.rs:15-69) <-> code i; 15/16/17 carry two integers parsed from the message
+    variants = ["InvalidParameters", "SamplingError", "EncryptionError", "DecryptionError", "KeyGenerationError", "CrsError",
+                "SerializationError", "DeserializationError", "EncodingError", "DecodingError", "ValidationError",
+                "ContextError", "PolynomialError", "MatrixError", "DimensionMismatch", "IndexOutOfBounds",
+                "InsufficientData", "InvalidFormat", "InternalError"]
+    codes = dict((int(v), k) for k, v in re.findall(r"(PVW_ERR_\w+) = (\d+)", HEADER))
+    body = SUPPORT[SUPPORT.index("pub fn check"):]
+    arms = re.findall(r"sys::(PVW_ERR_\w+) =>\s*(?:\{[^}]*?)?PvwError::(\w+)", body, flags=re.S)
+    mapped = dict(arms)
+    for code in range(1, 19):
+        assert mapped.get(codes[code]) == variants[code - 1], (code, codes[code], mapped.get(codes[code]))
+    assert re.search(r"_ => PvwError::InternalError", body)                 # 19 and anything newer
+    for name, fields in (("DimensionMismatch", "expected, actual"), ("IndexOutOfBounds", "index, bound"),
+                         ("InsufficientData", "expected, actual")):
+        assert re.search(r"PvwError::" + name + r" \{ " + fields + r" \}", body), name
+    # the Python mirror agrees on the names
+    from pvw_rs_amd import _ffi
+    assert [_ffi.ERROR_NAMES[i] for i in range(1, 20)] == variants
+
+
+def test_shims_cover_the_reference_surface_on_the_path():
+    # the functions VERDICT r01 #6 names, with the reference's signatures (src/lib.rs:14-55)
+    src = {f: open(os.path.join(ROOT, "rust", "pvw", "src", f)).read() for f in ("crs.rs", "keys.rs", "crypto.rs")}
+    for needle in ("pub fn new<R: RngCore + CryptoRng>(params: &Arc<PvwParameters>, rng: &mut R) -> Result<Self>",
+                   "pub fn new_from_tag(params: &Arc<PvwParameters>, tag: &str) -> Result<Self>",
+                   "pub fn new_deterministic("):
+        assert needle in src["crs.rs"], needle
+    for needle in ("pub fn add_public_key(&mut self, index: usize, public_key: PublicKey) -> Result<()>",
+                   "pub fn generate_and_add_party<R: RngCore + CryptoRng>(&mut self, party: &Party, rng: &mut R) -> Result<()>",
+                   "pub fn generate_all_party_keys(&mut self, parties: &[Party]) -> Result<()>", "sys::pvw_keygen("):
+        assert needle in src["keys.rs"], needle
+    for needle in ("pub fn encrypt(scalars: &[u64], global_pk: &GlobalPublicKey) -> Result<PvwCiphertext>",
+                   "pub fn encrypt_all_party_shares(all_shares: &[Vec<u64>], global_pk: &GlobalPublicKey) -> Result<Vec<PvwCiphertext>>",
+                   "pub fn decrypt_party_value(ciphertext: &PvwCiphertext, secret_key: &SecretKey, party_index: usize) -> Result<u64>",
+                   "pub fn decrypt_party_shares(all_ciphertexts: &[PvwCiphertext], secret_key: &SecretKey, party_index: usize) -> Result<Vec<u64>>",
+                   "pub fn encrypt_broadcast(scalar: u64, global_pk: &GlobalPublicKey) -> Result<PvwCiphertext>"):
+        assert needle in src["crypto.rs"], needle
+    for f, text in src.items():
+        assert "NOT COMPILED here" in text, f
