@@ -18,6 +18,17 @@ extern "C" {
  * inner products (crs.rs:188-201, encryption.rs:177-200) over the resident public-key section */
 PVW_API int32_t pvw_selftest_read_bandwidth(pvw_ctx* ctx, uint32_t reps, double* seconds_per_pass, uint64_t* bytes_per_pass);
 
+/* MEASUREMENT AID (tools/probe_sweep.py): the read probe with `u` tiles of 1 KiB (2u when dbuf != 0) in flight per wave
+ * and lds_bytes of unused LDS per workgroup, which caps the workgroups resident per CU */
+PVW_API int32_t pvw_tuning_read_probe(pvw_ctx* ctx, uint32_t reps, uint32_t u, uint32_t dbuf, uint32_t lds_bytes,
+                                      double* seconds_per_pass, uint64_t* bytes_per_pass);
+/* MEASUREMENT AID (tools/mac_timeline.py): with PVW_MAC_VARIANT=40 (default schedule) or 41 every workgroup of the
+ * streamed-inner-product kernel records its first and last instruction on the constant 100 MHz counter; this reads
+ * them back: stamps [count][2], hw_id [count] (HW_ID register of the workgroup's first wave: XCC, SE, CU). */
+PVW_API int32_t pvw_tuning_read_stamps(pvw_ctx* ctx, uint64_t* stamps, uint32_t* hw_id, uint32_t count);
+/* persistent form (PVW_MAC_VARIANT=42 / 43): per workgroup [b][2] = (tick of its first instruction, XCC_ID << 32 | HW_ID) */
+PVW_API int32_t pvw_tuning_read_wg_stamps(pvw_ctx* ctx, uint64_t* stamps, uint32_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,9 @@ _SIGNATURES = {
 # include/pvw_hip_tuning.h: exported by the measurement build only
 _TUNING_SIGNATURES = {
     "pvw_selftest_read_bandwidth": [_P, C.c_uint32, _P, _P],
+    "pvw_tuning_read_stamps": [_P, _P, _P, C.c_uint32],
+    "pvw_tuning_read_wg_stamps": [_P, _P, C.c_uint32],
+    "pvw_tuning_read_probe": [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P],
 }
 
 LIB_TUNING_PATH = os.path.join(HERE, "libpvw_hip_tuning.so")

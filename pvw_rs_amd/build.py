@@ -61,6 +61,8 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = True) -> st
         extra = ["-DPVW_TUNING=1"]
         if os.environ.get("PVW_GEMM_ABLATE"):          # compile-time ablation bits of the digit GEMM (tuning build only)
             extra.append("-DPVW_GEMM_ABLATE=" + os.environ["PVW_GEMM_ABLATE"])
+        if os.environ.get("PVW_GEMM_RPW"):             # row tiles per wave of the digit GEMM (experiment)
+            extra.append("-DPVW_GEMM_RPW=" + os.environ["PVW_GEMM_RPW"])
         jobs.append((LIB_TUNING,) + _build_one(LIB_TUNING, extra, "_tuning", verbose))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     for lib, objs, procs in jobs:

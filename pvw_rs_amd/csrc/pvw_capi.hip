@@ -408,8 +408,8 @@ static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
   PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
   w->rhat_bytes = 4 * k * P * 8;
   PVW_HIP(hipMemset(w->rhat, 0, w->rhat_bytes));          // recycled device memory may hold an earlier owner's data
-  PVW_HIP(hipMalloc((void**)&w->counters, 256));
-  PVW_HIP(hipMemset(w->counters, 0, 256));
+  PVW_HIP(hipMalloc((void**)&w->counters, 2048));          // 8 shard counters + 1, one per 128-byte line
+  PVW_HIP(hipMemset(w->counters, 0, 2048));
   return PVW_OK;
 }
 static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
@@ -1556,6 +1556,52 @@ int32_t pvw_selftest_read_bandwidth(pvw_ctx* c, uint32_t reps, double* seconds_p
   if (b) hipEventDestroy(b);
   ws_release(c, w);
   return rc;
+}
+// MEASUREMENT AID: the read probe with U tiles (2U when dbuf) in flight per wave and lds_bytes of dead LDS per
+// workgroup (caps the workgroups resident per CU): bandwidth against bytes in flight
+int32_t pvw_tuning_read_probe(pvw_ctx* c, uint32_t reps, uint32_t u, uint32_t dbuf, uint32_t lds_bytes, double* seconds_per_pass,
+                              uint64_t* bytes_per_pass) {
+  if (!c || !seconds_per_pass || !bytes_per_pass || reps == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(ensure_device(c));
+  if (!c->dB || c->rowsB() == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "no public key section resident");
+  Workspace* w;
+  PVW_TRY(ws_acquire(c, &w));
+  const size_t tiles = c->tiled_words(c->rowsB()) / 128;
+  const u32 tpw = c->k >= 128 ? (c->k / 4 / 32) * 32 : 32;
+  int32_t rc = ws_scratch(w, ((tiles + 63) / 64 + 1) * 8);
+  hipEvent_t a = nullptr, b = nullptr;
+  if (rc == PVW_OK && (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)) rc = fail(PVW_ERR_INTERNAL, "event");
+  if (rc == PVW_OK) {
+    bool ok = launch_read_probe2(c->dB, tiles, tpw, (u64*)w->scratch, u, dbuf != 0, lds_bytes, w->stream) == hipSuccess;
+    ok = ok && hipEventRecord(a, w->stream) == hipSuccess;
+    for (uint32_t i = 0; ok && i < reps; ++i)
+      ok = launch_read_probe2(c->dB, tiles, tpw, (u64*)w->scratch, u, dbuf != 0, lds_bytes, w->stream) == hipSuccess;
+    ok = ok && hipEventRecord(b, w->stream) == hipSuccess && hipEventSynchronize(b) == hipSuccess;
+    float ms = 0;
+    ok = ok && hipEventElapsedTime(&ms, a, b) == hipSuccess;
+    if (!ok) rc = fail(PVW_ERR_INTERNAL, "read probe failed");
+    *seconds_per_pass = (double)ms * 1e-3 / reps;
+    *bytes_per_pass = (uint64_t)tiles * 1024;
+  }
+  if (a) hipEventDestroy(a);
+  if (b) hipEventDestroy(b);
+  ws_release(c, w);
+  return rc;
+}
+// MEASUREMENT AID: start / end stamps of the workgroups of the last mac_rows launch made with PVW_MAC_VARIANT=40 / 41
+int32_t pvw_tuning_read_stamps(pvw_ctx* c, uint64_t* stamps, uint32_t* hw_id, uint32_t count) {
+  if (!c || !stamps || !hw_id) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(ensure_device(c));
+  PVW_HIP(hipDeviceSynchronize());
+  PVW_HIP(read_stamps(stamps, hw_id, count));
+  return PVW_OK;
+}
+int32_t pvw_tuning_read_wg_stamps(pvw_ctx* c, uint64_t* stamps, uint32_t count) {
+  if (!c || !stamps) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  PVW_TRY(ensure_device(c));
+  PVW_HIP(hipDeviceSynchronize());
+  PVW_HIP(read_wg_stamps(stamps, count));
+  return PVW_OK;
 }
 #endif  // PVW_TUNING
 

@@ -113,6 +113,7 @@ struct PrologueBatch {   // sizeof must stay below the 4 KiB kernel-argument lim
   u32 reps;    // 0 is read as 1
   u32 total;   // filled in by the launcher (polynomials per replica)
   u32 debug;   // filled in by the launcher (timing experiments)
+  u32 key_window, key_rep;   // filled in by the launcher: replica r reads keys [r * key_rep, r * key_rep + key_window)
 };
 hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s);
 
@@ -135,7 +136,9 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
                               hipStream_t s);
 
 // ---- digit GEMM on the matrix cores (see pvw_kernels.hip) ----
+#ifndef PVW_GEMM_RPW
 #define PVW_GEMM_RPW 1                                   // row tiles (of 32 rows) per wave
+#endif
 #define PVW_GEMM_ROWS_PER_WG (4 * PVW_GEMM_RPW * 32)     // 4 waves per workgroup
 // XM = MFMA-tiled copy of a matrix section: [limb][slot][row tile of 32][j block of 4][64 lanes][2 u64],
 // row tiles padded to whole workgroups (4 waves x PVW_GEMM_RPW row tiles).
@@ -177,7 +180,12 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
                               hipStream_t s);
 // read-only probe: every wave streams `tiles` consecutive 1-KiB tiles (16 in flight), grid as mac_rows
 #if PVW_TUNING
+// time stamps (100 MHz ticks, [2b] start / [2b+1] end) and HW_ID words of the workgroups of the last stamped mac_rows launch
+hipError_t read_stamps(u64* out, u32* hw, u32 count);
+hipError_t read_wg_stamps(u64* out, u32 count);   // persistent form: (kernel entry tick, XCC_ID << 32 | HW_ID) per workgroup
 hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, hipStream_t s);
+hipError_t launch_read_probe2(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, u32 U, bool dbuf, u32 lds_bytes,
+                              hipStream_t s);
 #endif
 // per-device kernel attributes (dynamic-LDS limits); call once per context after hipSetDevice
 hipError_t init_kernel_attributes();

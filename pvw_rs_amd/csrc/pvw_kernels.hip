@@ -32,12 +32,31 @@ typedef u64 v2u64 __attribute__((ext_vector_type(2)));  // one 16-byte lane acce
 // grid = row_blocks * L workgroups of 256 threads; the 4 waves split the j range, each
 // streaming a contiguous run of 1-KiB tiles; r-hat slices are staged in wave-private LDS.
 // ------------------------------------------------------------------------------------
+#if PVW_TUNING
+// per-workgroup time stamps of one stamped launch (tuning build, PVW_MAC_VARIANT 40 / 41): [2b] = first instruction,
+// [2b+1] = last store issued, in ticks of the constant 100 MHz counter (s_memrealtime); hw[b] = HW_ID of wave 0
+#define PVW_STAMP_MAX 65536
+__device__ u64 g_stamp_buf[2 * PVW_STAMP_MAX];
+__device__ u32 g_stamp_hw[PVW_STAMP_MAX];
+__device__ u64 g_stamp_wg[2 * 4096];       // persistent form: [2b] = kernel entry of workgroup b, [2b+1] = its HW_ID
+#endif
 // WPE: minimum waves per SIMD the register allocation must leave room for (1 = unconstrained).  ARITH (tuning build,
 // timing experiments only, wrong results): 2 = the modular MAC, 1 = one of the two MACs per 16 bytes, 0 = an xor.
-template <int ELL, int U, bool NT, bool DBUF, bool ILV = false, int NW = 4, int WPE = 1, int ARITH = 2>
+// STAMP (tuning build): record start / end times of every workgroup.
+template <int ELL, int U, bool NT, bool DBUF, bool ILV = false, int NW = 4, int WPE = 1, int ARITH = 2, bool STAMP = false>
 __global__ __launch_bounds__(NW * 64, WPE) void mac_rows_kernel(MacSection sa, MacSection sb,
                                                         const u64* __restrict__ rhat,
                                                         const Mod* __restrict__ mods, u32 k, u32 L) {
+#if PVW_TUNING
+  if constexpr (STAMP) {
+    if (threadIdx.x == 0 && blockIdx.x < PVW_STAMP_MAX) {
+      g_stamp_buf[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+      // XCC_ID (hardware register 20, low 4 bits) in bits 28..31 of the word, the CU / SE fields of HW_ID below it
+      g_stamp_hw[blockIdx.x] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 28) |
+                               (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) & 0x0fffffffu);
+    }
+  }
+#endif
   constexpr int HALF = ELL / 2;   // 16-byte slot pairs per polynomial limb
   constexpr int R = 128 / ELL;    // rows per tile
   constexpr int JC = ELL <= 16 ? 64 : (ELL == 32 ? 32 : 16);  // j per staged r-hat chunk (LDS <= 32 KiB)
@@ -191,34 +210,61 @@ __global__ __launch_bounds__(NW * 64, WPE) void mac_rows_kernel(MacSection sa, M
       reinterpret_cast<v2u64*>(out)[out_o] = s;
     }
   }
+#if PVW_TUNING
+  if constexpr (STAMP) {
+    if (threadIdx.x == 0 && blockIdx.x < PVW_STAMP_MAX) g_stamp_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
 // mac_rows, persistent form.  The grid is sized to what the chip holds at once (workgroups per CU x CUs) and every
-// workgroup walks work items (row block, limb) handed out by a device-side counter, so a slot never idles between
-// two items while the dispatcher tears one workgroup down and sets the next one up, and the last item's
-// epilogue (Barrett, cross-wave sum, addend, store) runs UNDER the first tile loads of the next item:
-//   * item i+1 is known while item i streams (the counter is popped one item ahead), so the last tile group of
-//     item i prefetches the first group and the r-hat slice of item i+1 instead of nothing;
-//   * partial sums alternate between two small LDS buffers, so one workgroup barrier per item is enough.
+// workgroup walks work items (row block, limb), so a slot never idles while the dispatcher tears one workgroup
+// down and sets the next one up, the epilogue of an item (Barrett, cross-wave sum, addend, store) runs UNDER the
+// first tile loads of the next one, and -- the point of the exercise -- the eight XCDs, which stream at rates up to
+// 8 % apart (profiles/r02_mac_timeline.txt: the hardware deals workgroups round-robin over them, so the one-
+// workgroup-per-item grid ends 13 us after its fastest XCD has run dry), share the tail of the work dynamically.
+//
+// Items are cut into NS = 8 contiguous shards; workgroup b belongs to shard b % NS (in practice: its XCD), rank
+// b / NS.  It first walks its STATIC share -- item lo + round * W + rank for the first two rounds, no communication
+// at all, so every workgroup starts at once and knows its first successor -- and then takes items from its shard's counter, and when that is exhausted from the other shards' counters
+// (one u32 per 128-byte line; a single global counter does not work: one address takes ~20 returning atomics
+// per microsecond under this load, which is the whole kernel's item rate).  The successor of an item is known
+// one item ahead, so the last tile group of item i prefetches the first group and the r-hat slice of item i+1.
+// Partial sums alternate between two small LDS buffers and the one barrier per item waits for LDS traffic only
+// (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() would also drain the prefetched tiles); the chunk count NC
+// is a template parameter so that an item is straight-line code and hipcc counts the outstanding loads exactly.
 // Same tiling, same lazy accumulation, same per-item arithmetic as mac_rows_kernel -- bit-identical results.
-// counters[0] = next item to hand out (every item, the first one of a workgroup included, comes from it: a
-// workgroup that becomes resident late simply takes what is left), counters[1] = workgroups that have finished;
-// the last one to finish re-arms both for the next launch on this stream (per-workspace counters: stream order
-// makes that safe).  Every workgroup terminates after at most items + 2 pops, whatever the dispatch order.
-// Needs k % (NW * U) == 0 and (k / NW) % JC == 0 or k / NW < JC handled by the launcher (else mac_rows_kernel).
+// Termination: a workgroup makes at most (its static rounds) + (pops that return an item) + NS failing pops.
+// counters: [s * 32] shard s, [NS * 32] workgroups finished; the last one to finish re-arms them all for the next
+// launch on this stream (per-workspace counters: stream order makes that safe).
 // ------------------------------------------------------------------------------------
-template <int ELL, int U, int WPE, int NW = 4>
+#define PVW_PERSIST_SHARDS 8
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+template <int ELL, int U, int WPE, int NC, int NW = 4, bool STAMP = false>
 __global__ __launch_bounds__(NW * 64, WPE) void mac_rows_persist_kernel(MacSection sa, MacSection sb,
                                                                 const u64* __restrict__ rhat,
                                                                 const Mod* __restrict__ mods, u32 k, u32 L,
-                                                                u32 items, u32* __restrict__ counters) {
+                                                                u32 items, u32 static_cap, u32* __restrict__ counters) {
+#if PVW_TUNING
+  if constexpr (STAMP) {
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+      g_stamp_wg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+      g_stamp_wg[2 * blockIdx.x + 1] = ((u64)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |
+                                       __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    }
+  }
+#endif
   constexpr int HALF = ELL / 2;
   constexpr int R = 128 / ELL;
   constexpr int JC = 256 / HALF;                 // tiles per r-hat chunk: 4 KiB slabs (64 at l = 8, 32 at l = 16, ...)
   constexpr int RN = JC * HALF / 64;             // = 4 sixteen-byte r-hat elements per lane per chunk
   constexpr int GPC = JC / U;                    // tile groups per chunk
-  static_assert(JC % U == 0 && GPC >= 1 && (GPC % 2 == 0 || GPC == 1), "groups are processed in pairs");
+  constexpr int NS = PVW_PERSIST_SHARDS;
+  constexpr u32 NONE = 0xffffffffu;
+  static_assert(JC % U == 0 && GPC >= 2 && GPC % 2 == 0, "groups are processed in pairs");
   __shared__ v2u64 slab[NW][JC * HALF];          // wave-private r-hat slices (a wave's LDS operations execute in order,
                                                  // so the next chunk's slice can overwrite the slab once the last
                                                  // multiply of the current chunk has been issued)
@@ -227,29 +273,50 @@ __global__ __launch_bounds__(NW * 64, WPE) void mac_rows_persist_kernel(MacSecti
 
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 sp = lane % HALF, rho = lane / HALF;
-  const u32 T = k / NW;                          // tiles per wave per item
-  const u32 NC = T / JC;                         // whole chunks per item (launcher guarantees T % JC == 0)
 
-  struct Item {           // everything here is wave-uniform (scalar registers)
-    const v2u64* mp;      // the wave's first tile of the item
-    const v2u64* rp;      // r-hat of the item's limb
-    u32 limb, rb;
-    bool in_a;
+  // ---- work distribution (everything here is workgroup-uniform) ----
+  const u32 W = gridDim.x / NS;                  // workgroups per shard (the launcher makes the grid a multiple of NS)
+  const u32 my_shard = blockIdx.x % NS, rank = blockIdx.x / NS;
+  auto shard_lo = [&](u32 sh) -> u32 { return (u32)(((u64)items * sh) / NS); };
+  auto static_rounds = [&](u32 sh) -> u32 {      // rounds of W items every workgroup of the shard takes unasked
+    const u32 full = (shard_lo(sh + 1) - shard_lo(sh)) / W;
+    return full < static_cap ? full : static_cap;
   };
-  auto setup = [&](u32 it) -> Item {
-    Item x;
-    x.limb = it % L;
-    const u32 rbg = it / L;
-    x.in_a = rbg < sa.row_blocks;
-    x.rb = x.in_a ? rbg : rbg - sa.row_blocks;
-    const u64* M = x.in_a ? sa.M : sb.M;
-    x.mp = reinterpret_cast<const v2u64*>(M + ((size_t)x.rb * L + x.limb) * (size_t)k * 128) + (size_t)wave * U * 64;
-    x.rp = reinterpret_cast<const v2u64*>(rhat + (size_t)x.limb * k * ELL);
-    return x;
+  u32 round = 0;                                 // static rounds taken so far
+  u32 steal = 0;                                 // shards found empty so far (thread 0 only meaningful)
+  const u32 my_static = static_rounds(my_shard);
+  // thread 0: next item from the counters, own shard first, then the others in turn
+  auto pop = [&]() -> u32 {
+    while (steal < (u32)NS) {
+      const u32 sh = (my_shard + steal) % NS;
+      const u32 base = shard_lo(sh) + static_rounds(sh) * W, hi = shard_lo(sh + 1);
+      const u32 v = atomicAdd(&counters[sh * 32], 1u);
+      if (base + v < hi) return base + v;
+      ++steal;
+    }
+    return NONE;
   };
+  // next item of this workgroup: arithmetic while the static share lasts, the counters afterwards
+  // (gen = parity of the LDS word the dynamic answer travels through)
+  auto next_static = [&]() -> u32 { return shard_lo(my_shard) + (round++) * W + rank; };
+
+  // an item's wave-uniform description, kept in separate scalars (a struct copied in the loop goes through the
+  // stack, and a kernel with a scratch segment ramps up an order of magnitude more slowly): the wave's first tile,
+  // the r-hat of the item's limb, limb, row block, section
+#define PVW_ITEM_DECL(P) const v2u64* P##mp; const v2u64* P##rp; u32 P##limb, P##rb; bool P##in_a
+#define PVW_ITEM_SETUP(P, it)                                                                                          \
+  do {                                                                                                                 \
+    P##limb = (it) % L;                                                                                                \
+    const u32 rbg_ = (it) / L;                                                                                         \
+    P##in_a = rbg_ < sa.row_blocks;                                                                                    \
+    P##rb = P##in_a ? rbg_ : rbg_ - sa.row_blocks;                                                                     \
+    const u64* M_ = P##in_a ? sa.M : sb.M;                                                                             \
+    P##mp = reinterpret_cast<const v2u64*>(M_ + ((size_t)P##rb * L + P##limb) * (size_t)k * 128) + (size_t)wave * U * 64; \
+    P##rp = reinterpret_cast<const v2u64*>(rhat + (size_t)P##limb * k * ELL);                                          \
+  } while (0)
   // local tile t of this wave is global tile (t / U) * NW * U + wave * U + t % U (the waves interleave groups of U)
-  auto ld_group = [&](const Item& it, u32 g, v2u64 (&dst)[U]) {
-    const v2u64* p = it.mp + (size_t)g * (NW * U * 64);     // scalar base; the lane offset is the only vector part
+  auto ld_group = [&](const v2u64* mp, u32 g, v2u64 (&dst)[U]) {
+    const v2u64* p = mp + (size_t)g * (NW * U * 64);        // scalar base; the lane offset is the only vector part
 #pragma unroll
     for (int u = 0; u < U; ++u) dst[u] = __builtin_nontemporal_load(p + u * 64 + lane);
   };
@@ -261,121 +328,143 @@ __global__ __launch_bounds__(NW * 64, WPE) void mac_rows_persist_kernel(MacSecti
     const u32 idx = lane + 64 * x, t = idx / HALF;            // t < JC: position inside a chunk
     roff[x] = ((t / U) * (NW * U) + wave * U + t % U) * HALF + idx % HALF;
   }
-  auto fetch_r = [&](const Item& it, u32 chunk, v2u64 (&rv)[RN]) {
-    const v2u64* p = it.rp + (size_t)chunk * (JC / U) * (NW * U) * HALF;   // whole groups per chunk (JC % U == 0)
+  auto fetch_r = [&](const v2u64* rp, u32 chunk, v2u64 (&rv)[RN]) {
+    const v2u64* p = rp + (size_t)chunk * (JC / U) * (NW * U) * HALF;     // whole groups per chunk (JC % U == 0)
 #pragma unroll
     for (int x = 0; x < RN; ++x) rv[x] = p[roff[x]];
   };
 
-  // the first two items in one pop; from then on the pop for item i+2 flies while item i streams
-  if (threadIdx.x == 0) nextslot[0] = atomicAdd(&counters[0], 2u);
-  __syncthreads();
-  u32 cur = __builtin_amdgcn_readfirstlane(nextslot[0]);   // item numbers are workgroup-uniform: keep them (and every
-                                                           // pointer derived from them) in scalar registers
-  if (cur >= items) {                            // nothing left: sign off
+  // ---- the first two items ----
+  u32 cur, nxt;
+  if (my_static >= 2) {
+    cur = next_static();
+    nxt = next_static();
+  } else {
     if (threadIdx.x == 0) {
-      const u32 done = atomicAdd(&counters[1], 1u);
-      if (done == gridDim.x - 1) { counters[0] = 0; counters[1] = 0; }
+      u32 a = my_static >= 1 ? next_static() : pop();
+      u32 b2 = a == NONE ? NONE : pop();
+      nextslot[0] = a;
+      nextslot[1] = b2;
     }
-    return;
+    __syncthreads();
+    cur = __builtin_amdgcn_readfirstlane(nextslot[0]);
+    nxt = __builtin_amdgcn_readfirstlane(nextslot[1]);
+    round = my_static;                           // the static share (0 or 1 item) is used up
+    __syncthreads();
   }
-  u32 nxt = cur + 1;
   u32 gen = 0;                                   // item generation: partial buffer / nextslot parity
-
-  Item ic = setup(cur);
-  v2u64 xa[U], xb[U], rv[RN];
-  fetch_r(ic, 0, rv);
-  ld_group(ic, 0, xa);
-
-  for (;;) {
-    u32 nn = 0;
-    if (threadIdx.x == 0) nn = atomicAdd(&counters[0], 1u);              // successor of nxt, needed at the barrier below
-    const bool have_next = nxt < items;          // workgroup-uniform
-    Item in = ic;
-    if (have_next) in = setup(nxt);
-    Acc a0, a1;
-    acc_zero(a0);
-    acc_zero(a1);
-    for (u32 c = 0; c < NC; ++c) {
-      v2u64* lw = slab[wave];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int x = 0; x < RN; ++x) lw[lane + 64 * x] = rv[x];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const bool last_chunk = c + 1 == NC;
-      // one group: prefetch what comes next into `nx`, multiply `cx` against the slab
-      auto group = [&](u32 g, v2u64 (&cx)[U], v2u64 (&nx)[U]) {
-        const bool last_in_chunk = g + 1 == (u32)GPC;
-        if (!last_in_chunk) {
-          ld_group(ic, c * GPC + g + 1, nx);
-        } else if (!last_chunk) {
-          fetch_r(ic, c + 1, rv);
-          ld_group(ic, (c + 1) * GPC, nx);
-        } else if (have_next) {
-          fetch_r(in, 0, rv);
-          ld_group(in, 0, nx);
+  if (cur != NONE) {
+    PVW_ITEM_DECL(c_);
+    PVW_ITEM_DECL(n_);
+    PVW_ITEM_SETUP(c_, cur);
+    v2u64 xa[U], xb[U], rv[RN];
+    fetch_r(c_rp, 0, rv);
+    ld_group(c_mp, 0, xa);
+    for (;;) {
+#if PVW_TUNING
+      if constexpr (STAMP) {
+        if (threadIdx.x == 0 && cur < PVW_STAMP_MAX) {
+          g_stamp_buf[2 * cur] = __builtin_amdgcn_s_memrealtime();
+          g_stamp_hw[cur] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 28) | (blockIdx.x & 0x0fffffffu);
         }
+      }
+#endif
+      // the item after `nxt`: arithmetic in the static phase; otherwise thread 0 asks the counters now and the
+      // answer is published at this item's barrier
+      const bool nn_static = round < my_static;  // uniform
+      u32 nn = NONE;
+      if (nn_static) nn = next_static();
+      else if (threadIdx.x == 0 && nxt != NONE) nn = pop();
+      const bool have_next = nxt != NONE;        // workgroup-uniform
+      PVW_ITEM_SETUP(n_, have_next ? nxt : cur);
+      // the addend of this lane's output (e1 / e2 + m*g, written by the prologue), requested before the tile stream
+      // so that at the end it is the oldest load in flight
+      const u32 nrows = c_in_a ? sa.nrows : sb.nrows;
+      const u64* addend = c_in_a ? sa.addend : sb.addend;
+      u64* out = c_in_a ? sa.out : sb.out;
+      const u32 out_row = c_rb * R + rho;
+      const size_t out_o = (((size_t)out_row * L + c_limb) * ELL) / 2 + sp;
+      v2u64 add_pf = (v2u64){0, 0};
+      if (wave == 0 && addend && out_row < nrows) add_pf = reinterpret_cast<const v2u64*>(addend)[out_o];
+      Acc a0, a1;
+      acc_zero(a0);
+      acc_zero(a1);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const v2u64 y = lw[(g * U + u) * HALF + sp];
-          acc_mac_dev(a0, cx[u].x, y.x);
-          acc_mac_dev(a1, cx[u].y, y.y);
-        }
-      };
-      if constexpr (GPC == 1) {
-        group(0, xa, xb);
+      for (int c = 0; c < NC; ++c) {
+        v2u64* lw = slab[wave];
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int u = 0; u < U; ++u) xa[u] = xb[u];
-      } else {
+        for (int x = 0; x < RN; ++x) lw[lane + 64 * x] = rv[x];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // one group: prefetch what comes next into `nx`, multiply `cx` against the slab
+        auto group = [&](int g, v2u64 (&cx)[U], v2u64 (&nx)[U]) {
+          if (g + 1 < GPC) {
+            ld_group(c_mp, c * GPC + g + 1, nx);
+          } else if (c + 1 < NC) {
+            fetch_r(c_rp, c + 1, rv);
+            ld_group(c_mp, (c + 1) * GPC, nx);
+          } else if (have_next) {
+            fetch_r(n_rp, 0, rv);
+            ld_group(n_mp, 0, nx);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const v2u64 y = lw[(g * U + u) * HALF + sp];
+            acc_mac_dev(a0, cx[u].x, y.x);
+            acc_mac_dev(a1, cx[u].y, y.y);
+          }
+        };
 #pragma unroll
         for (int g = 0; g < GPC; g += 2) {
           group(g, xa, xb);
           group(g + 1, xb, xa);
         }
       }
-    }
-    // epilogue of item `cur` (its successor's first loads are in flight): one Barrett per wave partial, cross-wave
-    // sum through LDS, addend, store
-    const Mod m = mods[ic.limb];
-    v2u64 pt;
-    pt.x = acc_reduce(a0, m);
-    pt.y = acc_reduce(a1, m);
-    part[gen][wave * 64 + lane] = pt;
-    if (threadIdx.x == 0) nextslot[gen ^ 1] = nn;
-    __syncthreads();
-    const u32 nn_all = __builtin_amdgcn_readfirstlane(nextslot[gen ^ 1]);
-    if (wave == 0) {
-      const u32 nrows = ic.in_a ? sa.nrows : sb.nrows;
-      const u64* addend = ic.in_a ? sa.addend : sb.addend;
-      u64* out = ic.in_a ? sa.out : sb.out;
-      const u32 out_row = ic.rb * R + rho;
-      if (out_row < nrows) {
-        v2u64 s = pt;
+      // epilogue of item `cur` (its successor's first loads are in flight): one Barrett per wave partial, cross-wave
+      // sum through LDS, addend, store
+      const Mod m = mods[c_limb];
+      v2u64 pt;
+      pt.x = acc_reduce(a0, m);
+      pt.y = acc_reduce(a1, m);
+      part[gen][wave * 64 + lane] = pt;
+      if (!nn_static && threadIdx.x == 0) nextslot[gen] = nn;
+      lds_barrier();
+      if (!nn_static) nn = __builtin_amdgcn_readfirstlane(nextslot[gen]);
+      if (wave == 0 && out_row < nrows) {
+        v2u64 sres = pt;
 #pragma unroll
         for (int w = 1; w < NW; ++w) {
           const v2u64 t = part[gen][w * 64 + lane];
-          s.x = addmod(s.x, t.x, m.q);
-          s.y = addmod(s.y, t.y, m.q);
+          sres.x = addmod(sres.x, t.x, m.q);
+          sres.y = addmod(sres.y, t.y, m.q);
         }
-        const size_t o = (((size_t)out_row * L + ic.limb) * ELL) / 2 + sp;
         if (addend) {
-          const v2u64 e = reinterpret_cast<const v2u64*>(addend)[o];
-          s.x = addmod(s.x, e.x, m.q);
-          s.y = addmod(s.y, e.y, m.q);
+          sres.x = addmod(sres.x, add_pf.x, m.q);
+          sres.y = addmod(sres.y, add_pf.y, m.q);
         }
-        reinterpret_cast<v2u64*>(out)[o] = s;
+        reinterpret_cast<v2u64*>(out)[out_o] = sres;
       }
+#if PVW_TUNING
+      if constexpr (STAMP) {
+        if (threadIdx.x == 0 && cur < PVW_STAMP_MAX) g_stamp_buf[2 * cur + 1] = __builtin_amdgcn_s_memrealtime();
+      }
+#endif
+      gen ^= 1;
+      if (!have_next) break;
+      cur = nxt;
+      nxt = nn;
+      c_mp = n_mp; c_rp = n_rp; c_limb = n_limb; c_rb = n_rb; c_in_a = n_in_a;
     }
-    gen ^= 1;
-    if (!have_next) break;
-    cur = nxt;
-    nxt = nn_all;
-    ic = in;
   }
+#undef PVW_ITEM_DECL
+#undef PVW_ITEM_SETUP
   if (threadIdx.x == 0) {
-    const u32 done = atomicAdd(&counters[1], 1u);
-    if (done == gridDim.x - 1) { counters[0] = 0; counters[1] = 0; }
+    const u32 done = atomicAdd(&counters[NS * 32], 1u);
+    if (done == gridDim.x - 1) {
+#pragma unroll
+      for (int sh = 0; sh <= NS; ++sh) counters[sh * 32] = 0;
+    }
   }
 }
 
@@ -804,40 +893,39 @@ __global__ __launch_bounds__(64) void sample_kernel(i64* __restrict__ out, ChaCh
 // polynomials, samples (or copies) their small coefficients into LDS with one thread per
 // polynomial, then one thread per (polynomial, limb) reduces, transforms and stores.
 // ------------------------------------------------------------------------------------
+// Latency is what this kernel is made of (one encrypt's worth is 4608 polynomials: a launch that cannot fill the chip
+// for long), so the dependent memory round trips are counted: the batch descriptor travels in the kernel-argument
+// segment (host memory behind PCIe unless the runtime keeps kernel arguments on the device -- every dependent read of
+// it costs microseconds) and is therefore read ONCE, by one wide load per workgroup into LDS; job look-ups after
+// that are LDS reads.  The inputs of the transform phase that live in device memory (the party's scalar, the limb's
+// modulus) are requested before the sampling phase and arrive under it.
+//   hop 1 scalar header (implicit)  ->  hop 2 descriptor -> LDS  ->  [ sampling || table staging, scalar / modulus
+//   loads ]  ->  transform  ->  store
 template <int ELL>
 __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u32 PB, u32 stage_tables, DevTables t) {
   extern __shared__ u64 psm[];
   i64* sc = reinterpret_cast<i64*>(psm);              // [PB][ELL] sampled coefficients
   u64* tab = psm + (size_t)PB * ELL;                  // [4][L][ELL] tw | twp | ghat | ghatp (if staged)
+  constexpr u32 JOB_WORDS = sizeof(PrologueJob) / 4, KEY_WORDS = sizeof(ChaChaKey) / 4;
+  static_assert(sizeof(PrologueJob) % 8 == 0, "descriptor copy is word-wise");
+  u32* jobw = reinterpret_cast<u32*>(tab + (stage_tables ? (size_t)4 * L * ELL : 0));   // [njobs] PrologueJob
+  u32* keyw = jobw + PVW_MAX_PROLOGUE_JOBS * JOB_WORDS;                                  // [key_window] ChaChaKey
+  const PrologueJob* jobs = reinterpret_cast<const PrologueJob*>(jobw);
+  const ChaChaKey* keys = reinterpret_cast<const ChaChaKey*>(keyw);
   const u32 gp0 = blockIdx.x * PB;
   const u32 tid = threadIdx.x;
   const u32 rep = blockIdx.y;                         // replica (dealer / party) of the template jobs
-  // locate (job, local polynomial) of global polynomial gp: jobs are laid end to end
-  auto locate = [&](u32 gp, u32& ji, u32& local) {
-    ji = 0;
-    local = gp;
-#pragma unroll
-    for (u32 x = 0; x + 1 < PVW_MAX_PROLOGUE_JOBS; ++x)
-      if (ji == x && x + 1 < b.njobs && local >= b.job[x].sj.count) { local -= b.job[x].sj.count; ji = x + 1; }
-  };
-  if (tid < PB && tid < 64 && gp0 + tid < b.total && !PVW_PDBG(b, 1)) {
-    u32 ji, local;
-    locate(gp0 + tid, ji, local);
-    const PrologueJob& job = b.job[ji];
-    i64* o = sc + tid * ELL;
-    if (job.explicit_coeffs) {
-      const i64* ec = job.explicit_coeffs + (size_t)rep * job.rep_coeffs;
-#pragma unroll
-      for (int s = 0; s < ELL; ++s) o[s] = ec[(size_t)local * ELL + s];
-    } else {
-      ChaChaRng g;
-      g.init(b.key[job.key_idx + rep * job.rep_key], job.sj.domain, job.sj.index0 + rep * job.rep_index0 + local);
-      auto emit = [o](u32 s, i64 v) { o[s] = v; };
-      if (job.sj.kind == SAMPLE_CBD) sample_cbd_poly(g, ELL, job.sj.cbd_half != 0, job.sj.cbd_v, emit);
-      else sample_uniform_poly(g, ELL, job.sj.bound, emit);
-    }
-  } else if (stage_tables && tid >= 64) {
-    // the three waves that do not sample bring the twiddle / gadget tables into LDS meanwhile
+  // ---- the descriptor: one coalesced read of the jobs and of this replica's key window ----
+  {
+    const u32* src = reinterpret_cast<const u32*>(&b.job[0]);
+    const u32 nw = b.njobs * JOB_WORDS;
+    for (u32 w = tid; w < nw; w += 256) jobw[w] = src[w];
+    const u32* ksrc = reinterpret_cast<const u32*>(&b.key[rep * b.key_rep]);
+    const u32 kw = b.key_window * KEY_WORDS;
+    for (u32 w = tid; w < kw; w += 256) keyw[w] = ksrc[w];
+  }
+  if (stage_tables && tid >= 64) {
+    // the three waves that do not sample bring the twiddle / gadget tables into LDS
     const u32 n = L * ELL;
     for (u32 x = tid - 64; x < n; x += 192) {
       tab[x] = t.tw[x];
@@ -847,16 +935,59 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
     }
   }
   __syncthreads();
+  // locate (job, local polynomial) of global polynomial gp: jobs are laid end to end
+  auto locate = [&](u32 gp, u32& ji, u32& local) {
+    ji = 0;
+    local = gp;
+#pragma unroll
+    for (u32 x = 0; x + 1 < PVW_MAX_PROLOGUE_JOBS; ++x)
+      if (ji == x && x + 1 < b.njobs && local >= jobs[x].sj.count) { local -= jobs[x].sj.count; ji = x + 1; }
+  };
+  // ---- this thread's (polynomial, limb) of the transform phase (first trip): request what it needs from device
+  // memory now, so that it arrives while wave 0 samples ----
+  const u32 p0 = tid / L, limb0 = tid % L;
+  const bool work0 = tid < PB * L && gp0 + p0 < b.total;
+  u32 ji0 = 0, local0 = 0;
+  Mod m0 = Mod{1, 0, 0};
+  u64 scalar0 = 0;
+  if (work0) {
+    locate(gp0 + p0, ji0, local0);
+    m0 = t.mods[limb0];
+    if (jobs[ji0].scalars) scalar0 = jobs[ji0].scalars[(size_t)rep * jobs[ji0].rep_scalars + local0];
+  }
+  if (tid < PB && tid < 64 && gp0 + tid < b.total && !PVW_PDBG(b, 1)) {
+    u32 ji, local;
+    locate(gp0 + tid, ji, local);
+    const PrologueJob& job = jobs[ji];
+    i64* o = sc + tid * ELL;
+    if (job.explicit_coeffs) {
+      const i64* ec = job.explicit_coeffs + (size_t)rep * job.rep_coeffs;
+#pragma unroll
+      for (int s = 0; s < ELL; ++s) o[s] = ec[(size_t)local * ELL + s];
+    } else {
+      ChaChaRng g;
+      g.init(keys[job.key_idx], job.sj.domain, job.sj.index0 + rep * job.rep_index0 + local);
+      auto emit = [o](u32 s, i64 v) { o[s] = v; };
+      if (job.sj.kind == SAMPLE_CBD) sample_cbd_poly(g, ELL, job.sj.cbd_half != 0, job.sj.cbd_v, emit);
+      else sample_uniform_poly(g, ELL, job.sj.bound, emit);
+    }
+  }
+  __syncthreads();
   if (PVW_PDBG(b, 2)) return;
   const u32 n = L * ELL;
   // one thread per (polynomial, limb); a block of PB <= 64 polynomials takes ceil(PB * L / 256) trips
   for (u32 idx = tid; idx < PB * L; idx += 256) {
     const u32 p = idx / L, limb = idx % L;
     if (gp0 + p >= b.total) break;
-    u32 ji, local;
-    locate(gp0 + p, ji, local);
-    const PrologueJob& job = b.job[ji];
-    const Mod m = t.mods[limb];
+    u32 ji = ji0, local = local0;
+    Mod m = m0;
+    u64 scalar = scalar0;
+    if (idx != tid) {                                    // later trips (PB * L > 256): the same look-ups, not prefetched
+      locate(gp0 + p, ji, local);
+      m = t.mods[limb];
+      scalar = jobs[ji].scalars ? jobs[ji].scalars[(size_t)rep * jobs[ji].rep_scalars + local] : 0;
+    }
+    const PrologueJob& job = jobs[ji];
     const u64* tw = stage_tables ? tab + (size_t)limb * ELL : t.tw + (size_t)limb * ELL;
     const u64* twp = stage_tables ? tab + n + (size_t)limb * ELL : t.twp + (size_t)limb * ELL;
     u64 a[ELL];
@@ -864,7 +995,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
     for (int s = 0; s < ELL; ++s) a[s] = signed_residue(sc[p * ELL + s], m);
     ntt_forward<ELL>(a, tw, twp, m);
     if (job.scalars) {
-      const u64 mr = signed_residue((i64)job.scalars[(size_t)rep * job.rep_scalars + local], m);   // `as i64` wrap, encryption.rs:195
+      const u64 mr = signed_residue((i64)scalar, m);     // `as i64` wrap, encryption.rs:195
       const u64* g = stage_tables ? tab + 2 * n + (size_t)limb * ELL : t.ghat + (size_t)limb * ELL;
       const u64* gp = stage_tables ? tab + 3 * n + (size_t)limb * ELL : t.ghatp + (size_t)limb * ELL;
 #pragma unroll
@@ -1819,10 +1950,13 @@ __global__ __launch_bounds__(256) void mftile_rows_kernel(const u64* __restrict_
   }
 }
 
-// vector elements -> digit tiles YD[vg][limb][slot][jb][h*32+col][16] and column sums SY.
+// vector elements -> digit tiles YD[vg][limb][slot][jb][h*32+col][16] and the offset correction SY.
 // One wave per (v, limb, slot); lane = j-block: each lane turns 4 consecutive j into the 8 shifted
-// copies y*2^(8a) mod q, writes their balanced digits as 16 16-byte runs, and the column sums are
-// reduced across the wave (no atomics).
+// copies y*2^(8a) mod q and writes their balanced digits as 16 16-byte runs.
+// The raw matrix bytes enter the MFMA offset by -128 (signed), so every output lacks 128 * sum_{j,a,b} d_b 2^(8b)
+// = 128 * sum_{j,a} (2^(8a) y_j mod q): a constant per (vector, limb, slot), because the balanced digits represent
+// each shifted copy exactly.  It is accumulated here from the copies themselves (wave-reduced, no atomics), reduced
+// mod q and left in SY as one u64 per vector (record of four per vector group); gemm_finish adds it.
 // 4x4 byte transpose of four dwords (y_i byte j = x_j byte i) with v_perm_b32
 __device__ __forceinline__ void transpose4x4_bytes(u32 x0, u32 x1, u32 x2, u32 x3, u32& y0, u32& y1, u32& y2, u32& y3) {
   const u32 t0 = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t1 = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
@@ -1846,7 +1980,8 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
   const u64 w256p = (m.ratio_hi << 8) | (m.ratio_lo >> 56);   // floor(256 * 2^64 / q) = floor(2^128 / q) >> 56
   const u64* y = vhat + (size_t)v * vstride + (size_t)limb * lstride + slot;
   signed char* tiles = YD + (((size_t)vg * L + limb) * ELL + slot) * (size_t)JB * 1024;
-  int colsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 csum_lo = 0;                                                // sum of the shifted copies (each < 2^62), 96 bits
+  u32 csum_hi = 0;
   __shared__ v4i32 st[STAGE ? 32 * 16 : 1];                     // [tile of this round][piece], 8 KiB
   const u32 jb_end = STAGE ? ((JB + 63) & ~63u) : JB;           // STAGE: whole passes, every lane takes part in the staging
   for (u32 jb = lane; jb < jb_end; jb += 64) {
@@ -1865,6 +2000,8 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
         const u64 dgt = (cur + C) ^ C;
         rl[a] = (u32)dgt;
         rh[a] = (u32)(dgt >> 32);
+        csum_lo += cur;
+        csum_hi += csum_lo < cur;
         cur = mulmod_shoup(cur, 256, w256p, m.q);
       }
       // 8x8 byte transpose: column b gets the bytes a = 0..7
@@ -1876,8 +2013,6 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         dg.d[b][jj] = ((u64)ch[b] << 32) | cl[b];
-        colsum[b] = __builtin_amdgcn_sdot4((int)cl[b], 0x01010101, colsum[b], false);
-        colsum[b] = __builtin_amdgcn_sdot4((int)ch[b], 0x01010101, colsum[b], false);
       }
     }
     if constexpr (STAGE) {
@@ -1918,22 +2053,18 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
       }
     }
   }
+  // wave sum of the 96-bit lane sums, then 128 * sum mod q
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    int sum = colsum[b];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    if (lane == 0) SY[(((size_t)vg * L + limb) * ELL + slot) * 32 + v4 * 8 + b] = sum;
+  for (int d = 32; d >= 1; d >>= 1) {
+    const u64 olo = ((u64)__shfl_xor((u32)(csum_lo >> 32), d) << 32) | __shfl_xor((u32)csum_lo, d);
+    const u32 ohi = __shfl_xor(csum_hi, d);
+    csum_lo += olo;
+    csum_hi += ohi + (csum_lo < olo);
   }
-}
-
-// value of lane (l ^ d), d in {1, 2, 4}, through DPP (no LDS crossbar): quad_perm for 1 and 2,
-// row_half_mirror (l ^ 7 within 8 lanes) followed by quad reversal (l ^ 3) for 4
-__device__ __forceinline__ int xor_lane_dpp(int v, int d) {
-  if (d == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-  if (d == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-  const int t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);        // row_half_mirror
-  return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, false);                // quad_perm [3,2,1,0]
+  if (lane == 0) {
+    const u64 r = reduce128(csum_lo, (u64)csum_hi, m);
+    reinterpret_cast<u64*>(SY + (((size_t)vg * L + limb) * ELL + slot) * 32)[v4] = mulmod(r, 128, m);
+  }
 }
 
 #if !PVW_TUNING
@@ -1986,10 +2117,6 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
     live[r] = ((rt0 + r) * 32) < sec.nrows;              // wave-uniform
   }
   const v4i32* ybase = reinterpret_cast<const v4i32*>(YD);
-  // column sums of the digit tiles (the +128 correction of the epilogue), requested up front
-  int sy_pf[NVG];
-#pragma unroll
-  for (int g = 0; g < NVG; ++g) sy_pf[g] = SY[(((size_t)g * L + limb) * ELL + slot) * 32 + (lane & 31)];
   v16i32 acc[RPW][NVG];
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
@@ -2056,8 +2183,11 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
         const v4i32 ax = ac[r][u];                          // XM holds the bytes already offset by -128
 #pragma unroll
         for (int g = 0; g < NVG; ++g) {
+          // the DIGIT tile is the first operand and the raw tile the second: the product comes out transposed,
+          // C[(v, b)][row], so a lane holds (for one matrix row) four digits b = 4h .. 4h+3 of four vectors in
+          // consecutive registers and the recombination below needs ONE exchange between the wave's halves
           if (PVW_ABL(32)) acc[r][g][0] += ax[0] ^ bf[u & 1][g][0];   // timing experiment: no MFMA
-          else acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ax, bf[u & 1][g], acc[r][g], 0, 0, 0);
+          else acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[u & 1][g], ax, acc[r][g], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -2082,11 +2212,14 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
       cur ^= 1;
     }
   }
-  // recombine: out[m][v] = sum_b (C[m][(v,b)] + 128*SY[(v,b)]) 2^(8b)  mod q.
-  // Lane (v, b) holds column b of 16 rows; three exchange steps across the 8 lanes of a vector leave lane b
-  // with the complete sums of rows `b` and `b+8` of its register file, which it reduces and stores.
+  // recombine: out[row][v] = sum_b C[(v, b)][row] 2^(8b)  mod q  (the offset correction is added by gemm_finish).
+  // Register 4 v4 + bb of lane (h, rr) holds digit b = 4 h + bb of vector v4 for matrix row rr: four registers
+  // give a 52-bit half-sum per vector by shifts and adds inside the lane, the lower half of the wave ending up
+  // with the LOW halves (digits 0-3) of four vectors and the upper half with their HIGH halves (digits 4-7).
+  // One exchange between the halves (v_permlane32_swap: upper half of one register <-> lower half of another)
+  // pairs them up: the lower lanes finish vectors 0 and 1, the upper lanes vectors 2 and 3.
   const Mod m = mods[limb];
-  const u32 h = lane >> 5, col = lane & 31, b = col & 7, v4 = col >> 3;
+  const u32 h = lane >> 5, rr = lane & 31;
   const double inv32 = 4294967296.0 / (double)m.q;           // FASTQ: every modulus is wider than 54 bits
   if (dbg & 2) {
     int keep = 0;
@@ -2102,62 +2235,35 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     if (!live[r]) continue;
+    const u32 row = (rt0 + r) * 32 + rr;
 #pragma unroll
     for (int g = 0; g < NVG; ++g) {
-      const u32 v = g * 4 + v4;
-      const int sy128 = 128 * sy_pf[g];
-      int x[16];
+      long long half[4];                                     // this lane's half-sum of vectors 4g .. 4g+3, |.| < 2^51
 #pragma unroll
-      for (int tt = 0; tt < 16; ++tt) x[tt] = acc[r][g][tt] + sy128;          // |.| < 2^26
-      // Weighted butterfly over the 8 lanes (b = 0..7) of one vector: at step d the lane with bit d of b
-      // clear keeps the registers whose index has bit d clear and adds its partner's copy times 2^(8d); the
-      // other lane keeps the rest.  After d = 1, 2 each lane holds 4 sums of four digits (< 2^52); the last
-      // exchange pairs the low half (digits 0-3) with the high half (digits 4-7) of registers b and b + 8.
-      // (the empty asm pins values in registers: without it hipcc folds the selects into a runtime register
-      // index and expands every access into a 16-way v_cndmask chain)
-      const bool up1 = (b & 1) != 0, up2 = (b & 2) != 0, up4 = (b & 4) != 0;
-      long long v1[8];
+      for (int v4 = 0; v4 < 4; ++v4)
+        half[v4] = (long long)acc[r][g][4 * v4] + ((long long)acc[r][g][4 * v4 + 1] << 8) +
+                   ((long long)acc[r][g][4 * v4 + 2] << 16) + ((long long)acc[r][g][4 * v4 + 3] << 24);
 #pragma unroll
-      for (int tq = 0; tq < 8; ++tq) {
-        int xe = x[2 * tq], xo = x[2 * tq + 1];
-        asm("" : "+v"(xe));
-        asm("" : "+v"(xo));
-        const int keep = up1 ? xo : xe, send = up1 ? xe : xo;
-        const int recv = xor_lane_dpp(send, 1);
-        const int lo_t = up1 ? recv : keep, hi_t = up1 ? keep : recv;
-        v1[tq] = (long long)lo_t + ((long long)hi_t << 8);
-      }
-      long long v2[4];
-#pragma unroll
-      for (int sq = 0; sq < 4; ++sq) {
-        long long ve = v1[2 * sq], vo = v1[2 * sq + 1];
-        asm("" : "+v"(ve));
-        asm("" : "+v"(vo));
-        const long long keep = up2 ? vo : ve, send = up2 ? ve : vo;
-        const long long recv = (long long)(((u64)(u32)xor_lane_dpp((int)((u64)send >> 32), 2) << 32) | (u32)xor_lane_dpp((int)(u32)send, 2));
-        const long long lo_t = up2 ? recv : keep, hi_t = up2 ? keep : recv;
-        v2[sq] = lo_t + (hi_t << 16);
-      }
-#pragma unroll
-      for (int z = 0; z < 2; ++z) {
-        long long ve = v2[2 * z], vo = v2[2 * z + 1];
-        asm("" : "+v"(ve));
-        asm("" : "+v"(vo));
-        const long long keep = up4 ? vo : ve, send = up4 ? ve : vo;
-        const long long recv = (long long)(((u64)(u32)xor_lane_dpp((int)((u64)send >> 32), 4) << 32) | (u32)xor_lane_dpp((int)(u32)send, 4));
-        const long long lo4 = up4 ? recv : keep, hi4 = up4 ? keep : recv;      // each |.| < 2^52
-        const u32 tt = b + 8 * z;
-        const u32 row = (rt0 + r) * 32 + (tt & 3) + 8 * (tt >> 2) + 4 * h;
+      for (int pr = 0; pr < 2; ++pr) {
+        // P = half[pr] (lower lanes keep their low part of vector pr, upper lanes give up their high part of it),
+        // Q = half[pr + 2] (lower lanes give up their low part of vector pr + 2, upper lanes keep their high part):
+        // after the swap every lane reads (low, high) = (P, Q) of the vector it finishes
+        const u64 P = (u64)half[pr], Q = (u64)half[pr + 2];
+        const auto slo = __builtin_amdgcn_permlane32_swap((u32)P, (u32)Q, false, false);
+        const auto shi = __builtin_amdgcn_permlane32_swap((u32)(P >> 32), (u32)(Q >> 32), false, false);
+        const long long lo4 = (long long)(((u64)shi[0] << 32) | slo[0]);
+        const long long hi4 = (long long)(((u64)shi[1] << 32) | slo[1]);
+        const u32 v = g * 4 + pr + 2 * h;
         u64 res;
         if constexpr (FASTQ) {
           // (lo4 + hi4 * 2^32) mod q for q > 2^53: |lo4| < q already; hi4 * 2^32 through a quotient estimated
           // in f64 (|hi4| < 2^52 is exact, the estimate is off by at most one) and two corrections
           const u64 ah = (u64)(hi4 < 0 ? -hi4 : hi4), al = (u64)(lo4 < 0 ? -lo4 : lo4);
           const u64 qhat = (u64)((double)ah * inv32);
-          long long rr = (long long)((ah << 32) - qhat * m.q);
-          if (rr < 0) rr += (long long)m.q;
-          if (rr >= (long long)m.q) rr -= (long long)m.q;
-          u64 rh = (u64)rr;
+          long long rem = (long long)((ah << 32) - qhat * m.q);
+          if (rem < 0) rem += (long long)m.q;
+          if (rem >= (long long)m.q) rem -= (long long)m.q;
+          u64 rh = (u64)rem;
           if (hi4 < 0 && rh) rh = m.q - rh;
           const u64 rl = (lo4 < 0 && al) ? m.q - al : al;
           res = addmod(rh, rl, m.q);
@@ -2169,7 +2275,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
           res = reduce128(lo, hi, m);
           if (neg && res) res = m.q - res;
         }
-        // intermediate [limb][slot][v][row]: the 16 lanes of one vector write 16 consecutive rows
+        // intermediate [limb][slot][v][row]: the 32 lanes of a half write 32 consecutive rows of one vector
         if (row < sec.nrows && v < nv)
           sec.tmp[vb * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res;
       }
@@ -2183,7 +2289,8 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 #define PVW_FINISH_VPB (ELL >= 64 ? 2 : 4)
 template <int ELL>
 __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const Mod* __restrict__ mods, u32 L,
-                                                           u32 nv, u32 nv_pad, u32 rows_pad, size_t ostride) {
+                                                           u32 nv, u32 nv_pad, u32 rows_pad, size_t ostride,
+                                                           const int* __restrict__ SY, size_t sy_b16) {
   constexpr int VPB = PVW_FINISH_VPB, PT = 32 * ELL / 256 ? 32 * ELL / 256 : 1;   // elements per thread per tile
   static_assert(sizeof(u64) * VPB * ELL * 33 <= 48 * 1024 || ELL > 32, "finish tiles");
   __shared__ u64 tile[VPB][ELL][33];
@@ -2211,6 +2318,10 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
   __syncthreads();
   const u64 q = mods[limb].q;
   u64 add[VPB][PT];
+  // offset correction of vector v at (limb, slot): SY record of its group of four (vec_digits_kernel)
+  auto corr_of = [&](u32 v, u32 slot) -> u64 {
+    return reinterpret_cast<const u64*>(SY + (size_t)(v >> 4) * sy_b16 + ((((size_t)((v & 15) >> 2)) * L + limb) * ELL + slot) * 32)[v & 3];
+  };
   const bool has_add = sec.addend != nullptr;
   const size_t rstride = sec.row_stride ? sec.row_stride : (size_t)L * ELL;
 #pragma unroll
@@ -2222,7 +2333,7 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
       const u32 v = (v0 + vi) < nv ? (v0 + vi) : (nv - 1);
       const u32 rr = (row0 + row) < sec.nrows ? (row0 + row) : 0;
       const size_t o = (size_t)v * ostride + (size_t)rr * rstride + (size_t)limb * ELL + slot;
-      add[vi][x] = has_add ? sec.addend[o] : 0;
+      add[vi][x] = addmod(has_add ? sec.addend[o] : 0, corr_of(v, slot), q);
     }
 #pragma unroll
   for (int vi = 0; vi < VPB; ++vi)
@@ -2273,6 +2384,46 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const u64* __restrict__
   if ((acc.x ^ acc.y) == 0x9e3779b97f4a7c15ULL) sink[blockIdx.x] = acc.x;   // keeps the loads alive
 }
 
+// the same with the number of tiles in flight per wave (U, and U + U when DBUF) and the workgroups resident per CU
+// (through a dynamic LDS allocation that is never read) as parameters: maps delivered bandwidth against bytes in flight
+template <int U, bool DBUF>
+__global__ __launch_bounds__(256) void read_probe2_kernel(const u64* __restrict__ M, size_t total_tiles, u32 tiles_per_wave,
+                                                           u64* __restrict__ sink) {
+  extern __shared__ u64 probe_pad[];
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t run0 = (size_t)blockIdx.x * 4 * tiles_per_wave;
+  const v2u64* p = reinterpret_cast<const v2u64*>(M) + lane;
+  v2u64 acc = (v2u64){0, 0};
+  const u32 G = tiles_per_wave / U;
+  auto ld = [&](u32 g, v2u64 (&x)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      size_t tile = run0 + (size_t)g * (4 * U) + wave * U + u;
+      tile = tile < total_tiles ? tile : total_tiles - 1;
+      x[u] = __builtin_nontemporal_load(p + tile * 64);
+    }
+  };
+  if constexpr (DBUF) {
+    v2u64 x[U], xn[U];
+    if (G) ld(0, x);
+    for (u32 g = 0; g < G; ++g) {
+      if (g + 1 < G) ld(g + 1, xn);
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= x[u];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = xn[u];
+    }
+  } else {
+    for (u32 g = 0; g < G; ++g) {
+      v2u64 x[U];
+      ld(g, x);
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= x[u];
+    }
+  }
+  if ((acc.x ^ acc.y) == 0x9e3779b97f4a7c15ULL) { sink[blockIdx.x] = acc.x; probe_pad[threadIdx.x] = acc.y; }
+}
+
 #endif  // PVW_TUNING
 
 // ------------------------------------------------------------------------------------
@@ -2295,25 +2446,36 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const u64* __restrict__
 static int mac_variant() {   // read per launch: the parity tests walk the variants in one process
   return (int)PVW_ENV_INT("PVW_MAC_VARIANT", 0);
 }
-// persistent form: grid = what the chip holds at once (occupancy query x CUs, capped by the item count)
-template <int E, int U, int WPE>
+// persistent form: grid = what the chip holds at once (occupancy query x CUs, a multiple of the shard count).
+// Returns false when the shape does not qualify (the caller then uses the one-workgroup-per-item kernel): k must
+// give every wave whole r-hat chunks (1, 2 or 4 of them), and there must be at least two items per resident
+// workgroup -- below that there is nothing to balance and the plain grid starts faster.
+template <int E, int U, int WPE, bool STAMP = false>
 static bool launch_mac_persist(dim3 grid, hipStream_t s, const MacSection& sa, const MacSection& sb, const u64* rhat,
                                const Mod* mods, u32 k, u32 L, u32* counters) {
   constexpr int HALF = E / 2, JC = 256 / HALF;
-  if constexpr (JC % U != 0 || ((JC / U) % 2 != 0 && JC / U != 1)) return false;
+  if constexpr (JC % U != 0 || (JC / U) % 2 != 0) return false;
   else {
     if (!counters || k % (4 * U) != 0 || (k / 4) % JC != 0) return false;
+    const u32 nc = (k / 4) / JC;
+    if (nc != 1 && nc != 2 && nc != 4) return false;
     static const int resident = [] {
       int dev = 0, cus = 0, per_cu = 0;
       if (hipGetDevice(&dev) != hipSuccess) return 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mac_rows_persist_kernel<E, U, WPE>, 256, 0) != hipSuccess) return 0;
-      return cus * per_cu;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mac_rows_persist_kernel<E, U, WPE, 1, 4, STAMP>, 256, 0) != hipSuccess) return 0;
+      return (cus * per_cu / PVW_PERSIST_SHARDS) * PVW_PERSIST_SHARDS;
     }();
-    if (resident <= 0) return false;
     const u32 items = grid.x;
-    const u32 wgs = items < (u32)resident ? items : (u32)resident;
-    mac_rows_persist_kernel<E, U, WPE><<<dim3(wgs), dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L, items, counters);
+    if (resident <= 0 || items < 2 * (u32)resident) return false;
+    // rounds every workgroup takes without asking (instant start, first successor known); everything after that
+    // comes from the shard counters: the XCDs stream at rates 10-20 % apart and which ones are slow changes from
+    // launch to launch, so nearly all of the work has to be up for grabs
+    const u32 dyn_rounds = (u32)PVW_ENV_INT("PVW_MAC_STATIC", 2);
+    const dim3 g((u32)resident);
+    if (nc == 1) mac_rows_persist_kernel<E, U, WPE, 1, 4, STAMP><<<g, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L, items, dyn_rounds, counters);
+    else if (nc == 2) mac_rows_persist_kernel<E, U, WPE, 2, 4, STAMP><<<g, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L, items, dyn_rounds, counters);
+    else mac_rows_persist_kernel<E, U, WPE, 4, 4, STAMP><<<g, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L, items, dyn_rounds, counters);
     return true;
   }
 }
@@ -2328,10 +2490,12 @@ static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacS
       case 21: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // timing only
       case 22: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 1><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // timing only
       case 23: if (k % 32 == 0) { mac_rows_kernel<E, 8, true, true, true, 4, 4><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 40: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 2, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // default schedule + stamps
+      case 41: if (k % 32 == 0) { mac_rows_kernel<E, 8, true, true, true, 4, 4, 2, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;    // U = 8, four waves per SIMD + stamps
+      case 42: if (launch_mac_persist<E, 16, 2, true>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;   // + per-item stamps
+      case 43: if (launch_mac_persist<E, 8, 3, true>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
       case 30: if (launch_mac_persist<E, 16, 2>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
-      case 31: if (launch_mac_persist<E, 8, 4>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
-      case 32: if (launch_mac_persist<E, 8, 3>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
-      case 33: if (launch_mac_persist<E, 16, 3>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
+      case 31: if (launch_mac_persist<E, 8, 3>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;
       case 1: mac_rows_kernel<E, 8, false, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       case 2: mac_rows_kernel<E, 4, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
       case 3: mac_rows_kernel<E, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return;
@@ -2471,10 +2635,15 @@ hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L
   if (b.njobs > PVW_MAX_PROLOGUE_JOBS) return hipErrorInvalidValue;
   if (b.reps == 0) b.reps = 1;
   if (b.reps > 65535) return hipErrorInvalidValue;
+  b.key_window = 1;
+  b.key_rep = b.njobs ? b.job[0].rep_key : 0;
   for (u32 i = 0; i < b.njobs; ++i) {
     b.total += b.job[i].sj.count;
     if (b.job[i].key_idx + (b.reps - 1) * b.job[i].rep_key >= PVW_MAX_PROLOGUE_KEYS) return hipErrorInvalidValue;
+    if (b.job[i].rep_key != b.key_rep) return hipErrorInvalidValue;     // one key policy per batch: shared, or one per replica
+    if (b.job[i].key_idx + 1 > b.key_window) b.key_window = b.job[i].key_idx + 1;
   }
+  if (b.key_window > 8) return hipErrorInvalidValue;
   if (b.total == 0) return hipSuccess;
   if (L > 256) return hipErrorInvalidValue;
   // polynomials per block: 256/L (one trip of the transform loop, lowest latency) for one encrypt's worth of
@@ -2484,8 +2653,9 @@ hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L
   if ((size_t)b.total * b.reps >= 65536) PB = 64;
   const u32 blocks = (b.total + PB - 1) / PB;
   const size_t sc_bytes = (size_t)PB * ell * 8, tab_bytes = (size_t)4 * L * ell * 8;
-  const u32 stage = (sc_bytes + tab_bytes <= 64 * 1024) ? 1u : 0u;
-  const size_t lds = sc_bytes + (stage ? tab_bytes : 0);
+  const size_t desc_bytes = (size_t)PVW_MAX_PROLOGUE_JOBS * sizeof(PrologueJob) + 8 * sizeof(ChaChaKey);
+  const u32 stage = (sc_bytes + tab_bytes + desc_bytes <= 64 * 1024) ? 1u : 0u;
+  const size_t lds = sc_bytes + (stage ? tab_bytes : 0) + desc_bytes;
   PVW_DISPATCH_ELL(ell, prologue_kernel<E><<<dim3(blocks, b.reps), dim3(256), lds, s>>>(b, L, PB, stage, t));
   return hipGetLastError();
 }
@@ -2691,21 +2861,45 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
 #undef PVW_GEMM_LAUNCH
   if (sa.nrows) {
     PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sa.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
-                              sa, t.mods, L, nv, nv_pad, sa.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_a));
+                              sa, t.mods, L, nv, nv_pad, sa.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_a, SY, sy_b16));
   }
   if (sb.nrows) {
     PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sb.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
-                              sb, t.mods, L, nv, nv_pad, sb.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_b));
+                              sb, t.mods, L, nv, nv_pad, sb.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_b, SY, sy_b16));
   }
   return hipGetLastError();
 }
 
 #if PVW_TUNING
+hipError_t read_wg_stamps(u64* out, u32 count) {
+  if (count > 4096) return hipErrorInvalidValue;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_wg), (size_t)count * 16, 0, hipMemcpyDeviceToHost);
+}
+hipError_t read_stamps(u64* out, u32* hw, u32 count) {
+  if (count > PVW_STAMP_MAX) return hipErrorInvalidValue;
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_buf), (size_t)count * 16, 0, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return e;
+  return hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_stamp_hw), (size_t)count * 4, 0, hipMemcpyDeviceToHost);
+}
 hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, hipStream_t s) {
   if (total_tiles == 0 || tiles_per_wave < 16) return hipErrorInvalidValue;
   const size_t per_wg = (size_t)4 * tiles_per_wave;
   const u32 blocks = (u32)((total_tiles + per_wg - 1) / per_wg);
   read_probe_kernel<<<dim3(blocks), dim3(256), 0, s>>>(M, total_tiles, tiles_per_wave, sink);
+  return hipGetLastError();
+}
+hipError_t launch_read_probe2(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, u32 U, bool dbuf, u32 lds_bytes,
+                              hipStream_t s) {
+  if (total_tiles == 0 || tiles_per_wave < U || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  const size_t per_wg = (size_t)4 * tiles_per_wave;
+  const u32 blocks = (u32)((total_tiles + per_wg - 1) / per_wg);
+#define PVW_PROBE2(Uv, Dv) read_probe2_kernel<Uv, Dv><<<dim3(blocks), dim3(256), lds_bytes, s>>>(M, total_tiles, tiles_per_wave, sink)
+  if (U == 8) { if (dbuf) PVW_PROBE2(8, true); else PVW_PROBE2(8, false); }
+  else if (U == 16) { if (dbuf) PVW_PROBE2(16, true); else PVW_PROBE2(16, false); }
+  else if (U == 32) { if (dbuf) return hipErrorInvalidValue; else PVW_PROBE2(32, false); }
+  else if (U == 4) { if (dbuf) PVW_PROBE2(4, true); else PVW_PROBE2(4, false); }
+  else return hipErrorInvalidValue;
+#undef PVW_PROBE2
   return hipGetLastError();
 }
 #endif  // PVW_TUNING
@@ -2727,6 +2921,13 @@ hipError_t init_kernel_attributes() {
   e = hipFuncSetAttribute((const void*)decode_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   if (e != hipSuccess) return e;
 #if PVW_TUNING
+  hipFuncSetAttribute((const void*)read_probe2_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)read_probe2_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)read_probe2_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)read_probe2_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)read_probe2_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)read_probe2_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)read_probe2_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   e = hipFuncSetAttribute((const void*)decode_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)decode_chain_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
