@@ -52,10 +52,10 @@ def _build_one(lib: str, extra, tag: str, verbose: bool):
     return objs, procs
 
 
-def build(force: bool = False, verbose: bool = False, tuning: bool = True) -> str:
+def build(force: bool = False, verbose: bool = False, tuning: bool = True, shipped: bool = True) -> str:
     """Builds whatever is stale (both libraries by default; the four hipcc compiles run side by side)."""
     jobs = []
-    if force or _stale(LIB):
+    if shipped and (force or _stale(LIB)):
         jobs.append((LIB,) + _build_one(LIB, [], "", verbose))
     if tuning and (force or _stale(LIB_TUNING)):
         extra = ["-DPVW_TUNING=1"]
@@ -77,4 +77,4 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = True) -> st
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="--quiet" not in sys.argv, shipped="--tuning-only" not in sys.argv))
