@@ -18,8 +18,9 @@ extern "C" {
  * inner products (crs.rs:188-201, encryption.rs:177-200) over the resident public-key section */
 PVW_API int32_t pvw_selftest_read_bandwidth(pvw_ctx* ctx, uint32_t reps, double* seconds_per_pass, uint64_t* bytes_per_pass);
 
-/* MEASUREMENT AID (tools/probe_sweep.py): the read probe with `u` tiles of 1 KiB (2u when dbuf != 0) in flight per wave
- * and lds_bytes of unused LDS per workgroup, which caps the workgroups resident per CU */
+/* MEASUREMENT AID (tools/probe_sweep.py): the read probe with `u` tiles of 1 KiB (2u when dbuf & 1) in flight per wave
+ * and lds_bytes of unused LDS per workgroup, which caps the workgroups resident per CU; dbuf & 2: every XCD walks a
+ * contiguous eighth of the matrix instead of every eighth 256-KiB run */
 PVW_API int32_t pvw_tuning_read_probe(pvw_ctx* ctx, uint32_t reps, uint32_t u, uint32_t dbuf, uint32_t lds_bytes,
                                       double* seconds_per_pass, uint64_t* bytes_per_pass);
 /* MEASUREMENT AID (tools/mac_timeline.py): with PVW_MAC_VARIANT=40 (default schedule) or 41 every workgroup of the

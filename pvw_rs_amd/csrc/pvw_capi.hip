@@ -118,6 +118,8 @@ struct Workspace {
   u64* rhat = nullptr;       // [L][k][l]  (x4: up to four r-hat / s-hat vectors)
   size_t rhat_bytes = 0;
   u32* counters = nullptr;   // work-queue words of the persistent mac_rows (zeroed once; the kernel re-arms them)
+  u64* dpart = nullptr;      // range sums of a split decrypt_mac [nsplit][dealers][L][l]
+  size_t dpart_bytes = 0;
   u64* scalars = nullptr;    // [n]
   u64* c1 = nullptr;         // [rowsA][L][l]
   u64* c2 = nullptr;         // [rowsB][L][l]
@@ -438,6 +440,7 @@ static void ws_free(Workspace* w) {
   if (w->scratch) hipMemset(w->scratch, 0, w->scratch_bytes);
   hipFree(w->rhat);
   hipFree(w->counters);
+  hipFree(w->dpart);
   hipFree(w->scalars);
   hipFree(w->c1);
   hipFree(w->c2);
@@ -1572,10 +1575,10 @@ int32_t pvw_tuning_read_probe(pvw_ctx* c, uint32_t reps, uint32_t u, uint32_t db
   hipEvent_t a = nullptr, b = nullptr;
   if (rc == PVW_OK && (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)) rc = fail(PVW_ERR_INTERNAL, "event");
   if (rc == PVW_OK) {
-    bool ok = launch_read_probe2(c->dB, tiles, tpw, (u64*)w->scratch, u, dbuf != 0, lds_bytes, w->stream) == hipSuccess;
+    bool ok = launch_read_probe2(c->dB, tiles, tpw, (u64*)w->scratch, u, (dbuf & 1) != 0, lds_bytes, w->stream, (dbuf >> 1) & 1) == hipSuccess;
     ok = ok && hipEventRecord(a, w->stream) == hipSuccess;
     for (uint32_t i = 0; ok && i < reps; ++i)
-      ok = launch_read_probe2(c->dB, tiles, tpw, (u64*)w->scratch, u, dbuf != 0, lds_bytes, w->stream) == hipSuccess;
+      ok = launch_read_probe2(c->dB, tiles, tpw, (u64*)w->scratch, u, (dbuf & 1) != 0, lds_bytes, w->stream, (dbuf >> 1) & 1) == hipSuccess;
     ok = ok && hipEventRecord(b, w->stream) == hipSuccess && hipEventSynchronize(b) == hipSuccess;
     float ms = 0;
     ok = ok && hipEventElapsedTime(&ms, a, b) == hipSuccess;
@@ -1670,6 +1673,33 @@ int32_t pvw_decode_device(pvw_ctx* c, const uint64_t* d_noisy, size_t count, uin
 }
 
 // ------------------------------------------------------------------------ decrypt
+// noisy[d] = INTT( sum_j s-hat[j] (.) c1s[d][j] - c2col[d] )  for D ciphertexts (decryption.rs:257-274, :116): the inner
+// products as one launch, cut into ranges of j when that gives the launch enough short workgroups (decrypt_split),
+// then the inverse transform (which adds the ranges up when there are any)
+static int32_t decrypt_mac_intt(pvw_ctx* c, Workspace* w, const u64* d_c1s, const u64* d_c2col, size_t D, u64* d_noisy,
+                                hipStream_t s) {
+  const u32 k = c->k, l = c->l, L = c->L;
+  const u32 ns = decrypt_split(k, L, l, D);
+  if (ns > 1) {
+    const size_t need = (size_t)ns * D * c->poly() * 8;
+    if (w->dpart_bytes < need) {
+      if (w->dpart) { PVW_HIP(hipStreamSynchronize(s)); hipFree(w->dpart); w->dpart = nullptr; w->dpart_bytes = 0; }
+      PVW_HIP(hipMalloc((void**)&w->dpart, need));
+      w->dpart_bytes = need;
+    }
+  }
+  {
+    ProfScope ps(c, "decrypt_mac", s);
+    PVW_HIP(launch_decrypt_mac(d_c1s, w->rhat, d_c2col, d_noisy, c->dt, k, L, l, D, s, w->dpart, ns));
+  }
+  {
+    ProfScope ps(c, "intt", s);
+    if (ns > 1) PVW_HIP(launch_decrypt_finish(w->dpart, ns, d_c2col, d_noisy, c->dt, L, l, D, s));
+    else PVW_HIP(launch_ntt(d_noisy, D, true, c->dt, L, l, s));
+  }
+  return PVW_OK;
+}
+
 static int32_t decrypt_enqueue(pvw_ctx* c, Workspace* w, const i64* d_sk, u64* d_c1s, u64* d_c2col, size_t D,
                                uint32_t in_repr, u64* d_noisy, hipStream_t s, bool inputs_mutable) {
   const u32 k = c->k, l = c->l, L = c->L;
@@ -1685,15 +1715,7 @@ static int32_t decrypt_enqueue(pvw_ctx* c, Workspace* w, const i64* d_sk, u64* d
     PVW_HIP(launch_ntt(d_c1s, D * k, false, c->dt, L, l, s));
     PVW_HIP(launch_ntt(d_c2col, D, false, c->dt, L, l, s));
   }
-  {
-    ProfScope ps(c, "decrypt_mac", s);
-    PVW_HIP(launch_decrypt_mac(d_c1s, w->rhat, d_c2col, d_noisy, c->dt, k, L, l, D, s));   // decryption.rs:257-274
-  }
-  {
-    ProfScope ps(c, "intt", s);
-    PVW_HIP(launch_ntt(d_noisy, D, true, c->dt, L, l, s));                                  // :116
-  }
-  return PVW_OK;
+  return decrypt_mac_intt(c, w, d_c1s, d_c2col, D, d_noisy, s);
 }
 // NTT(sk) sits in w->rhat while a decrypt runs: cleared on the call's stream behind the last kernel that read it
 static int32_t wipe_shat(pvw_ctx* c, Workspace* w, hipStream_t s) {
@@ -1758,14 +1780,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
   for (size_t i = 0; i < nch; ++i) {
     const size_t d0 = i * chunk, cnt = (D - d0) < chunk ? (D - d0) : chunk;
     u64* nz = d_noisy + d0 * P;
-    {
-      ProfScope ps(c, "decrypt_mac", s);
-      PVW_HIP(launch_decrypt_mac(d_c1s + d0 * k * P, w->rhat, d_c2col + d0 * P, nz, c->dt, k, L, l, cnt, s));   // decryption.rs:257-274
-    }
-    {
-      ProfScope ps(c, "intt", s);
-      PVW_HIP(launch_ntt(nz, cnt, true, c->dt, L, l, s));                                                        // :116
-    }
+    PVW_TRY(decrypt_mac_intt(c, w, d_c1s + d0 * k * P, d_c2col + d0 * P, cnt, nz, s));                          // decryption.rs:257-274, :116
     hipStream_t ds = s;
     if (overlap) {
       PVW_HIP(hipEventRecord(w->events[i], s));

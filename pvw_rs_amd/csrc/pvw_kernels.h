@@ -131,9 +131,15 @@ hipError_t launch_sample(i64* out, const ChaChaKey& key, u32 ell, const SampleJo
                          const SampleJob& j1, const SampleJob& j2, hipStream_t s);
 hipError_t launch_gaussian(i64* out, const ChaChaKey& key, u32 index0, u32 count, u64 bound,
                            hipStream_t s);
+// nsplit > 1 (from decrypt_split; `partial` then holds nsplit x dealers polynomials): the k terms are cut into nsplit
+// ranges whose sums go to `partial`; launch_decrypt_finish adds them up, subtracts c2 and transforms back.
+// nsplit <= 1: noisy = <s-hat, c1> - c2 in the NTT domain, as before (follow with launch_ntt(inverse)).
+u32 decrypt_split(u32 k, u32 L, u32 ell, size_t dealers);
 hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col, u64* noisy,
                               const DevTables& t, u32 k, u32 L, u32 ell, size_t dealers,
-                              hipStream_t s);
+                              hipStream_t s, u64* partial = nullptr, u32 nsplit = 1);
+hipError_t launch_decrypt_finish(const u64* partial, u32 nsplit, const u64* c2col, u64* noisy, const DevTables& t, u32 L, u32 ell,
+                                 size_t dealers, hipStream_t s);
 
 // ---- digit GEMM on the matrix cores (see pvw_kernels.hip) ----
 #ifndef PVW_GEMM_RPW
@@ -185,7 +191,7 @@ hipError_t read_stamps(u64* out, u32* hw, u32 count);
 hipError_t read_wg_stamps(u64* out, u32 count);   // persistent form: (kernel entry tick, XCC_ID << 32 | HW_ID) per workgroup
 hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, hipStream_t s);
 hipError_t launch_read_probe2(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, u32 U, bool dbuf, u32 lds_bytes,
-                              hipStream_t s);
+                              hipStream_t s, u32 xmap = 0);
 #endif
 // per-device kernel attributes (dynamic-LDS limits); call once per context after hipSetDevice
 hipError_t init_kernel_attributes();

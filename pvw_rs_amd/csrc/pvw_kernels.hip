@@ -43,7 +43,10 @@ __device__ u64 g_stamp_wg[2 * 4096];       // persistent form: [2b] = kernel ent
 // WPE: minimum waves per SIMD the register allocation must leave room for (1 = unconstrained).  ARITH (tuning build,
 // timing experiments only, wrong results): 2 = the modular MAC, 1 = one of the two MACs per 16 bytes, 0 = an xor.
 // STAMP (tuning build): record start / end times of every workgroup.
-template <int ELL, int U, bool NT, bool DBUF, bool ILV = false, int NW = 4, int WPE = 1, int ARITH = 2, bool STAMP = false>
+// XMAP: which item a block takes.  0: item = block id (the hardware deals blocks round-robin over the XCDs, so an XCD
+// walks the matrix with a stride of 8 items = 2 MiB at k = 256).  1: every XCD gets a contiguous eighth of the items.
+// 2: eighths interleaved in pairs of items.
+template <int ELL, int U, bool NT, bool DBUF, bool ILV = false, int NW = 4, int WPE = 1, int ARITH = 2, bool STAMP = false, int XMAP = 0>
 __global__ __launch_bounds__(NW * 64, WPE) void mac_rows_kernel(MacSection sa, MacSection sb,
                                                         const u64* __restrict__ rhat,
                                                         const Mod* __restrict__ mods, u32 k, u32 L) {
@@ -64,8 +67,16 @@ __global__ __launch_bounds__(NW * 64, WPE) void mac_rows_kernel(MacSection sa, M
   static_assert(JC * HALF >= 64, "the wave partials reuse the r-hat slabs");
 
   // section a = A-hat rows (c1), section b = B-hat rows (c2): one launch covers both
-  const u32 limb = blockIdx.x % L;
-  const u32 rbg = blockIdx.x / L;
+  u32 item = blockIdx.x;
+  if constexpr (XMAP == 1) {
+    const u32 per = gridDim.x >> 3, tail = gridDim.x & 7;       // blocks beyond a multiple of 8 keep their id
+    if (item < gridDim.x - tail) item = (item & 7) * per + (item >> 3);
+  } else if constexpr (XMAP == 2) {
+    const u32 per = (gridDim.x >> 4) << 1, lim = per << 3;
+    if (item < lim) { const u32 q = item >> 1, e = item & 1; item = (q & 7) * per + ((q >> 3) << 1) + e; }
+  }
+  const u32 limb = item % L;
+  const u32 rbg = item / L;
   const bool in_a = rbg < sa.row_blocks;
   const u32 rb = in_a ? rbg : rbg - sa.row_blocks;
   const u64* __restrict__ M = in_a ? sa.M : sb.M;
@@ -1151,14 +1162,19 @@ __global__ __launch_bounds__(1024) void decrypt_mac_kernel(const u64* __restrict
 // decrypt_mac, dealer-grouped form: one workgroup serves DG dealers, so every s-hat pair fetched
 // (through L2) is used DG times and the vector-memory instruction count per streamed byte drops
 // from 2 to 1 + 1/DG.  Thread (g, e) as above; UJ j-steps are issued together.
+// gridDim.y > 1 (both forms): the k terms are cut into gridDim.y ranges; a workgroup then leaves the partial sum of
+// its range in partial[range][dealer] (no c2) and decrypt_finish_kernel adds the ranges up -- small batches
+// (a single decrypt_party_value is ONE workgroup otherwise) then spread over the chip.
 template <int DG, int UJ, int MAXT, bool NO_S = false>
 __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __restrict__ c1s,
                                                                     const u64* __restrict__ shat,
                                                                     const u64* __restrict__ c2col,
                                                                     u64* __restrict__ noisy,
-                                                                    const Mod* __restrict__ mods, u32 k,
-                                                                    u32 ell, u32 pairs, u32 c, u32 dealers) {
+                                                                    const Mod* __restrict__ mods, u32 k_all,
+                                                                    u32 ell, u32 pairs, u32 c, u32 dealers, u64* __restrict__ partial) {
   extern __shared__ v2u64 dl[];
+  const u32 kq = (k_all + gridDim.y - 1) / gridDim.y, jlo = blockIdx.y * kq;
+  const u32 k = (jlo + kq) < k_all ? (jlo + kq) : k_all;       // this workgroup's terms: [jlo, k)
   const u32 d0 = blockIdx.x * DG;
   const u32 g = threadIdx.x / pairs, e = threadIdx.x % pairs;
   const bool active = threadIdx.x < c * pairs;
@@ -1167,13 +1183,13 @@ __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __
 #pragma unroll
   for (int dd = 0; dd < DG; ++dd) {
     const u32 d = (d0 + dd) < dealers ? (d0 + dd) : (dealers - 1);   // clamp: tail group re-reads the last dealer
-    cp[dd] = reinterpret_cast<const v2u64*>(c1s) + (size_t)d * k * pairs + e;
+    cp[dd] = reinterpret_cast<const v2u64*>(c1s) + (size_t)d * k_all * pairs + e;
   }
   Acc a0[DG], a1[DG];
 #pragma unroll
   for (int dd = 0; dd < DG; ++dd) { acc_zero(a0[dd]); acc_zero(a1[dd]); }
   if (active) {
-    u32 j = g;
+    u32 j = jlo + g;
     for (; j + (UJ - 1) * c < k; j += UJ * c) {
       v2u64 y[UJ], x[UJ][DG];
 #pragma unroll
@@ -1219,10 +1235,14 @@ __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __
         sres.y = addmod(sres.y, t.y, m.q);
       }
       const size_t o = (size_t)(d0 + dd) * pairs + e;
-      v2u64 c2 = reinterpret_cast<const v2u64*>(c2col)[o];
-      sres.x = submod(sres.x, c2.x, m.q);
-      sres.y = submod(sres.y, c2.y, m.q);
-      reinterpret_cast<v2u64*>(noisy)[o] = sres;
+      if (gridDim.y > 1) {
+        reinterpret_cast<v2u64*>(partial)[(size_t)blockIdx.y * dealers * pairs + o] = sres;
+      } else {
+        v2u64 c2 = reinterpret_cast<const v2u64*>(c2col)[o];
+        sres.x = submod(sres.x, c2.x, m.q);
+        sres.y = submod(sres.y, c2.y, m.q);
+        reinterpret_cast<v2u64*>(noisy)[o] = sres;
+      }
     }
   }
 }
@@ -1241,10 +1261,12 @@ __global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restr
                                                                const u64* __restrict__ shat,
                                                                const u64* __restrict__ c2col,
                                                                u64* __restrict__ noisy,
-                                                               const Mod* __restrict__ mods, u32 k, u32 ell,
+                                                               const Mod* __restrict__ mods, u32 k_all, u32 ell,
                                                                u32 pairs, u32 FW, u32 cfull, u32 remp, u32 crem,
-                                                               u32 dealers) {
+                                                               u32 dealers, u64* __restrict__ partial) {
   extern __shared__ v2u64 dl[];                        // [DG][waves*64] partial sums
+  const u32 kq = (k_all + gridDim.y - 1) / gridDim.y, jlo = blockIdx.y * kq;
+  const u32 k = (jlo + kq) < k_all ? (jlo + kq) : k_all;       // this workgroup's terms: [jlo, k)
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 nfull = cfull * FW, rem = pairs - FW * 64;
   const bool is_full = wave < nfull;                   // wave-uniform
@@ -1270,13 +1292,13 @@ __global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restr
 #pragma unroll
   for (int dd = 0; dd < DG; ++dd) {
     const u32 d = (d0 + dd) < dealers ? (d0 + dd) : (dealers - 1);
-    cp[dd] = reinterpret_cast<const v2u64*>(c1s) + (size_t)d * k * pairs + (active ? e : 0);
+    cp[dd] = reinterpret_cast<const v2u64*>(c1s) + (size_t)d * k_all * pairs + (active ? e : 0);
   }
   Acc a0[DG], a1[DG];
 #pragma unroll
   for (int dd = 0; dd < DG; ++dd) { acc_zero(a0[dd]); acc_zero(a1[dd]); }
   if (active) {
-    u32 j = jstart;
+    u32 j = jlo + jstart;
     for (; j + (UJ - 1) * jstep < k; j += UJ * jstep) {
       v2u64 y[UJ], x[UJ][DG];
 #pragma unroll
@@ -1340,12 +1362,46 @@ __global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restr
           }
       }
       const size_t o = (size_t)(d0 + dd) * pairs + e;
-      v2u64 c2 = reinterpret_cast<const v2u64*>(c2col)[o];
-      sres.x = submod(sres.x, c2.x, m.q);
-      sres.y = submod(sres.y, c2.y, m.q);
-      reinterpret_cast<v2u64*>(noisy)[o] = sres;
+      if (gridDim.y > 1) {
+        reinterpret_cast<v2u64*>(partial)[(size_t)blockIdx.y * dealers * pairs + o] = sres;
+      } else {
+        v2u64 c2 = reinterpret_cast<const v2u64*>(c2col)[o];
+        sres.x = submod(sres.x, c2.x, m.q);
+        sres.y = submod(sres.y, c2.y, m.q);
+        reinterpret_cast<v2u64*>(noisy)[o] = sres;
+      }
     }
   }
+}
+
+// decrypt_finish: noisy[d] = INTT( sum_r partial[r][d] - c2col[d] )   (decryption.rs:268-274 and the
+// change_representation(PowerBasis) of :116), one thread per (dealer, limb): the range sums of a split decrypt_mac
+// are added up where the inverse transform reads them anyway
+template <int ELL>
+__global__ __launch_bounds__(64) void decrypt_finish_kernel(const u64* __restrict__ partial, u32 nsplit,
+                                                             const u64* __restrict__ c2col, u64* __restrict__ noisy,
+                                                             u32 dealers, u32 L, DevTables t) {
+  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= dealers * L) return;
+  const u32 limb = tid % L;
+  const Mod m = t.mods[limb];
+  const size_t o = (size_t)tid * ELL, plane = (size_t)dealers * L * ELL;
+  u64 a[ELL];
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2) {
+    const v2u64 c2 = *reinterpret_cast<const v2u64*>(c2col + o + s);
+    v2u64 acc = *reinterpret_cast<const v2u64*>(partial + o + s);
+    for (u32 r = 1; r < nsplit; ++r) {
+      const v2u64 p = *reinterpret_cast<const v2u64*>(partial + r * plane + o + s);
+      acc.x = addmod(acc.x, p.x, m.q);
+      acc.y = addmod(acc.y, p.y, m.q);
+    }
+    a[s] = submod(acc.x, c2.x, m.q);
+    a[s + 1] = submod(acc.y, c2.y, m.q);
+  }
+  ntt_inverse<ELL>(a, t.itw + (size_t)limb * ELL, t.itwp + (size_t)limb * ELL, t.linv[limb], t.linvp[limb], m);
+#pragma unroll
+  for (int s = 0; s < ELL; s += 2) *reinterpret_cast<v2u64*>(noisy + o + s) = (v2u64){a[s], a[s + 1]};
 }
 
 // ------------------------------------------------------------------------------------
@@ -2388,10 +2444,15 @@ __global__ __launch_bounds__(256) void read_probe_kernel(const u64* __restrict__
 // (through a dynamic LDS allocation that is never read) as parameters: maps delivered bandwidth against bytes in flight
 template <int U, bool DBUF>
 __global__ __launch_bounds__(256) void read_probe2_kernel(const u64* __restrict__ M, size_t total_tiles, u32 tiles_per_wave,
-                                                           u64* __restrict__ sink) {
+                                                           u64* __restrict__ sink, u32 xmap) {
   extern __shared__ u64 probe_pad[];
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t run0 = (size_t)blockIdx.x * 4 * tiles_per_wave;
+  u32 item = blockIdx.x;
+  if (xmap) {                                                 // every XCD a contiguous eighth of the runs (see mac_rows XMAP)
+    const u32 per = gridDim.x >> 3, tail = gridDim.x & 7;
+    if (item < gridDim.x - tail) item = (item & 7) * per + (item >> 3);
+  }
+  const size_t run0 = (size_t)item * 4 * tiles_per_wave;
   const v2u64* p = reinterpret_cast<const v2u64*>(M) + lane;
   v2u64 acc = (v2u64){0, 0};
   const u32 G = tiles_per_wave / U;
@@ -2490,6 +2551,8 @@ static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacS
       case 21: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // timing only
       case 22: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 1><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // timing only
       case 23: if (k % 32 == 0) { mac_rows_kernel<E, 8, true, true, true, 4, 4><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 50: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 2, false, 1><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // XCD-contiguous items
+      case 51: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 2, true, 1><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;    // + stamps
       case 40: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 2, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // default schedule + stamps
       case 41: if (k % 32 == 0) { mac_rows_kernel<E, 8, true, true, true, 4, 4, 2, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;    // U = 8, four waves per SIMD + stamps
       case 42: if (launch_mac_persist<E, 16, 2, true>(grid, s, sa, sb, rhat, mods, k, L, counters)) return; break;   // + per-item stamps
@@ -2667,10 +2730,37 @@ hipError_t launch_gaussian(i64* out, const ChaChaKey& key, u32 index0, u32 count
   return hipGetLastError();
 }
 
+// how many ranges of j a decrypt over `dealers` ciphertexts is cut into (1 = no split): enough workgroups to put one
+// on every CU when the batch alone does not, never ranges shorter than 64 terms
+u32 decrypt_split(u32 k, u32 L, u32 ell, size_t dealers) {
+  const u32 pairs = L * ell / 2;
+  if (pairs > 1024 || dealers == 0) return 1;            // the generic form does not split
+  u32 ns = (u32)PVW_ENV_INT("PVW_DEC_SPLIT", 0);          // tuning build: forced split
+  if (ns == 0) {
+    // measured at config 5 (profiles/r02_decrypt_split.txt): once every CU has a workgroup, cutting the ranges only
+    // costs (356 -> 370 / 377 / 387 us at 2 / 4 / 8 ranges); the split is for small batches -- a single
+    // decrypt_party_value is one workgroup streaming k polynomials alone otherwise
+    const size_t wgs = (dealers + 1) / 2;
+    ns = wgs >= 256 ? 1 : (u32)((256 + wgs - 1) / wgs);
+    if (ns > 8) ns = 8;
+  }
+  while (ns > 1 && (k + ns - 1) / ns < 64) --ns;
+  return ns ? ns : 1;
+}
+
+hipError_t launch_decrypt_finish(const u64* partial, u32 nsplit, const u64* c2col, u64* noisy, const DevTables& t, u32 L, u32 ell,
+                                 size_t dealers, hipStream_t s) {
+  if (dealers == 0) return hipSuccess;
+  const u32 threads = (u32)dealers * L;
+  PVW_DISPATCH_ELL(ell, decrypt_finish_kernel<E><<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(partial, nsplit, c2col, noisy, (u32)dealers, L, t));
+  return hipGetLastError();
+}
+
 hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col, u64* noisy,
                               const DevTables& t, u32 k, u32 L, u32 ell, size_t dealers,
-                              hipStream_t s) {
+                              hipStream_t s, u64* partial, u32 nsplit) {
   if (dealers == 0) return hipSuccess;
+  if (nsplit == 0 || !partial) nsplit = 1;
   const u32 pairs = L * ell / 2;
   u32 step, c, threads, ny;
   if (pairs <= 1024) {
@@ -2716,8 +2806,8 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
     if (waves >= 1 && waves <= 16) {
       const u32 thr = waves * 64;
 #define PVW_DEC_FW(DGv, UJv)                                                                                       \
-  decrypt_mac_fw_kernel<DGv, UJv><<<dim3((u32)((dealers + DGv - 1) / DGv)), dim3(thr), (size_t)DGv * thr * sizeof(v2u64), s>>>( \
-      c1s, shat, c2col, noisy, t.mods, k, ell, pairs, FW, cfull, remp, crem, (u32)dealers)
+  decrypt_mac_fw_kernel<DGv, UJv><<<dim3((u32)((dealers + DGv - 1) / DGv), nsplit), dim3(thr), (size_t)DGv * thr * sizeof(v2u64), s>>>( \
+      c1s, shat, c2col, noisy, t.mods, k, ell, pairs, FW, cfull, remp, crem, (u32)dealers, partial)
 #if PVW_TUNING
       switch (variant) {
         case 61: PVW_DEC_FW(2, 4); break;
@@ -2738,11 +2828,11 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
 #define PVW_DEC_GROUPED(DGv, UJv)                                                                         \
   do {                                                                                                    \
     if (threads <= 512)                                                                                   \
-      decrypt_mac_grouped_kernel<DGv, UJv, 512><<<dim3((u32)((dealers + DGv - 1) / DGv)), dim3(threads), lds, s>>>( \
-          c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers);                                \
+      decrypt_mac_grouped_kernel<DGv, UJv, 512><<<dim3((u32)((dealers + DGv - 1) / DGv), nsplit), dim3(threads), lds, s>>>( \
+          c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers, partial);                       \
     else                                                                                                  \
-      decrypt_mac_grouped_kernel<DGv, UJv, 1024><<<dim3((u32)((dealers + DGv - 1) / DGv)), dim3(threads), lds, s>>>( \
-          c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers);                                \
+      decrypt_mac_grouped_kernel<DGv, UJv, 1024><<<dim3((u32)((dealers + DGv - 1) / DGv), nsplit), dim3(threads), lds, s>>>( \
+          c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers, partial);                       \
   } while (0)
 #if PVW_TUNING
     switch (variant) {
@@ -2754,8 +2844,8 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
       case 40: PVW_DEC_GROUPED(3, 2); break;
       case 41: PVW_DEC_GROUPED(4, 2); break;
       case 50:   // timing experiment only (wrong results): the c1 stream without the s-hat loads
-        decrypt_mac_grouped_kernel<2, 2, 512, true><<<dim3((u32)((dealers + 1) / 2)), dim3(threads), lds, s>>>(
-            c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers);
+        decrypt_mac_grouped_kernel<2, 2, 512, true><<<dim3((u32)((dealers + 1) / 2), nsplit), dim3(threads), lds, s>>>(
+            c1s, shat, c2col, noisy, t.mods, k, ell, pairs, c, (u32)dealers, partial);
         break;
       default: PVW_DEC_GROUPED(2, 2); break;
     }
@@ -2889,11 +2979,11 @@ hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wav
   return hipGetLastError();
 }
 hipError_t launch_read_probe2(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, u32 U, bool dbuf, u32 lds_bytes,
-                              hipStream_t s) {
+                              hipStream_t s, u32 xmap) {
   if (total_tiles == 0 || tiles_per_wave < U || lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   const size_t per_wg = (size_t)4 * tiles_per_wave;
   const u32 blocks = (u32)((total_tiles + per_wg - 1) / per_wg);
-#define PVW_PROBE2(Uv, Dv) read_probe2_kernel<Uv, Dv><<<dim3(blocks), dim3(256), lds_bytes, s>>>(M, total_tiles, tiles_per_wave, sink)
+#define PVW_PROBE2(Uv, Dv) read_probe2_kernel<Uv, Dv><<<dim3(blocks), dim3(256), lds_bytes, s>>>(M, total_tiles, tiles_per_wave, sink, xmap)
   if (U == 8) { if (dbuf) PVW_PROBE2(8, true); else PVW_PROBE2(8, false); }
   else if (U == 16) { if (dbuf) PVW_PROBE2(16, true); else PVW_PROBE2(16, false); }
   else if (U == 32) { if (dbuf) return hipErrorInvalidValue; else PVW_PROBE2(32, false); }

@@ -67,6 +67,8 @@ DECRYPT_CONFIGS: Dict[str, Tuple[int, int, int, int, str]] = {
     "c5shard": (1024, 512, 16, 34, "BASELINE configs[4] per-GPU shard: D=8192/8 dealer ciphertexts, k=512, l=16, 2074-bit q"),
     "c5full": (8192, 512, 16, 34, "BASELINE configs[4] in full on ONE GPU: D=8192 dealer ciphertexts, k=512, l=16, 2074-bit q (18.3 GB)"),
     "d3": (2048, 256, 8, 17, "decrypt of D=2048 dealer ciphertexts at the config-3 geometry: k=256, l=8, 1037-bit q"),
+    "c5one": (1, 512, 16, 34, "one decrypt_party_value at the config-5 geometry (latency): k=512, l=16, 2074-bit q"),
+    "c5x16": (16, 512, 16, 34, "16 dealer ciphertexts at the config-5 geometry: k=512, l=16, 2074-bit q"),
 }
 
 # synthetic inputs: CRS / public-key / encrypt seeds, builder defaults (parameters.rs:166-168)

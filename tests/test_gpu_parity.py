@@ -367,6 +367,9 @@ DECRYPT_SHAPE_CASES = [
     (64, 8, 17, 7),       # 68 pairs (configs 2/3): one full wave + a 4-pair remainder
     (9, 8, 3, 3),         # 12 pairs: remainder waves only
     (11, 16, 8, 2),       # 64 pairs: no remainder
+    (300, 16, 34, 5),     # 272 pairs, k = 300: the inner products are cut into four ragged ranges of j (75 terms)
+    (256, 8, 17, 6),      # 68 pairs (dealer-grouped form), four ranges of 64
+    (512, 16, 4, 3),      # eight ranges of 64
 ]
 
 

@@ -30,7 +30,7 @@ def run(u, dbuf, wgs):
 
 print(f"config {cfg}: B-hat {p.resident_bytes()[1] / 1e9:.3f} GB; columns: U dbuf WGs/CU(cap) -> GB/s, us per pass")
 for rep in range(2):
-    for u, dbuf in ((4, 0), (4, 1), (8, 0), (8, 1), (16, 0), (16, 1), (32, 0)):
+    for u, dbuf in ((4, 0), (4, 1), (8, 0), (8, 1), (16, 0), (16, 1), (32, 0), (8, 2), (16, 2), (16, 3)):   # dbuf & 2: XCD-contiguous runs
         row = []
         for wgs in (0, 8, 6, 5, 4, 3, 2, 1):
             g, us = run(u, dbuf, wgs)
