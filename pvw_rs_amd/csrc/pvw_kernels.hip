@@ -2123,6 +2123,54 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
   }
 }
 
+// One 32x32 accumulator of the digit GEMM (digit tile as first operand: register 4 v4 + bb of lane (h, rr) holds
+// digit b = 4 h + bb of vector v4 for matrix row rr) -> the two finished sums this lane owns,
+//   res[pr] = sum_b C[(v, b)][row] 2^(8b) mod q   for v = pr + 2 h  (pr = 0, 1).
+// Four registers give a 52-bit half-sum per vector by shifts and adds inside the lane, the lower half of the wave
+// ending up with the LOW halves (digits 0-3) of four vectors and the upper half with their HIGH halves (digits 4-7).
+// One exchange between the halves (v_permlane32_swap: upper half of one register <-> lower half of another) pairs
+// them up: the lower lanes finish vectors 0 and 1, the upper lanes vectors 2 and 3.
+template <bool FASTQ>
+__device__ __forceinline__ void gemm_recombine(const v16i32& a, const Mod& m, double inv32, u64 (&res)[2]) {
+  long long half[4];                                     // this lane's half-sum of the four vectors, |.| < 2^51
+#pragma unroll
+  for (int v4 = 0; v4 < 4; ++v4)
+    half[v4] = (long long)a[4 * v4] + ((long long)a[4 * v4 + 1] << 8) + ((long long)a[4 * v4 + 2] << 16) +
+               ((long long)a[4 * v4 + 3] << 24);
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    // P = half[pr] (lower lanes keep their low part of vector pr, upper lanes give up their high part of it),
+    // Q = half[pr + 2] (lower lanes give up their low part of vector pr + 2, upper lanes keep their high part):
+    // after the swap every lane reads (low, high) = (P, Q) of the vector it finishes
+    const u64 P = (u64)half[pr], Q = (u64)half[pr + 2];
+    const auto slo = __builtin_amdgcn_permlane32_swap((u32)P, (u32)Q, false, false);
+    const auto shi = __builtin_amdgcn_permlane32_swap((u32)(P >> 32), (u32)(Q >> 32), false, false);
+    const long long lo4 = (long long)(((u64)shi[0] << 32) | slo[0]);
+    const long long hi4 = (long long)(((u64)shi[1] << 32) | slo[1]);
+    if constexpr (FASTQ) {
+      // (lo4 + hi4 * 2^32) mod q for q > 2^53: |lo4| < q already; hi4 * 2^32 through a quotient estimated
+      // in f64 (|hi4| < 2^52 is exact, the estimate is off by at most one) and two corrections
+      const u64 ah = (u64)(hi4 < 0 ? -hi4 : hi4), al = (u64)(lo4 < 0 ? -lo4 : lo4);
+      const u64 qhat = (u64)((double)ah * inv32);
+      long long rem = (long long)((ah << 32) - qhat * m.q);
+      if (rem < 0) rem += (long long)m.q;
+      if (rem >= (long long)m.q) rem -= (long long)m.q;
+      u64 rh = (u64)rem;
+      if (hi4 < 0 && rh) rh = m.q - rh;
+      const u64 rl = (lo4 < 0 && al) ? m.q - al : al;
+      res[pr] = addmod(rh, rl, m.q);
+    } else {
+      const __int128 tot = (__int128)lo4 + ((__int128)hi4 << 32);
+      u64 lo = (u64)tot, hi = (u64)((unsigned __int128)tot >> 64);
+      const bool neg = (long long)hi < 0;
+      if (neg) { lo = ~lo + 1; hi = ~hi + (lo == 0); }
+      u64 r = reduce128(lo, hi, m);
+      if (neg && r) r = m.q - r;
+      res[pr] = r;
+    }
+  }
+}
+
 #if !PVW_TUNING
 #undef PVW_GEMM_ABLATE
 #endif
@@ -2268,12 +2316,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
       cur ^= 1;
     }
   }
-  // recombine: out[row][v] = sum_b C[(v, b)][row] 2^(8b)  mod q  (the offset correction is added by gemm_finish).
-  // Register 4 v4 + bb of lane (h, rr) holds digit b = 4 h + bb of vector v4 for matrix row rr: four registers
-  // give a 52-bit half-sum per vector by shifts and adds inside the lane, the lower half of the wave ending up
-  // with the LOW halves (digits 0-3) of four vectors and the upper half with their HIGH halves (digits 4-7).
-  // One exchange between the halves (v_permlane32_swap: upper half of one register <-> lower half of another)
-  // pairs them up: the lower lanes finish vectors 0 and 1, the upper lanes vectors 2 and 3.
+  // recombine (gemm_recombine): out[row][v] = sum_b C[(v, b)][row] 2^(8b) mod q; the offset correction is added by gemm_finish
   const Mod m = mods[limb];
   const u32 h = lane >> 5, rr = lane & 31;
   const double inv32 = 4294967296.0 / (double)m.q;           // FASTQ: every modulus is wider than 54 bits
@@ -2294,46 +2337,143 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
     const u32 row = (rt0 + r) * 32 + rr;
 #pragma unroll
     for (int g = 0; g < NVG; ++g) {
-      long long half[4];                                     // this lane's half-sum of vectors 4g .. 4g+3, |.| < 2^51
-#pragma unroll
-      for (int v4 = 0; v4 < 4; ++v4)
-        half[v4] = (long long)acc[r][g][4 * v4] + ((long long)acc[r][g][4 * v4 + 1] << 8) +
-                   ((long long)acc[r][g][4 * v4 + 2] << 16) + ((long long)acc[r][g][4 * v4 + 3] << 24);
+      u64 res[2];
+      gemm_recombine<FASTQ>(acc[r][g], m, inv32, res);
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        // P = half[pr] (lower lanes keep their low part of vector pr, upper lanes give up their high part of it),
-        // Q = half[pr + 2] (lower lanes give up their low part of vector pr + 2, upper lanes keep their high part):
-        // after the swap every lane reads (low, high) = (P, Q) of the vector it finishes
-        const u64 P = (u64)half[pr], Q = (u64)half[pr + 2];
-        const auto slo = __builtin_amdgcn_permlane32_swap((u32)P, (u32)Q, false, false);
-        const auto shi = __builtin_amdgcn_permlane32_swap((u32)(P >> 32), (u32)(Q >> 32), false, false);
-        const long long lo4 = (long long)(((u64)shi[0] << 32) | slo[0]);
-        const long long hi4 = (long long)(((u64)shi[1] << 32) | slo[1]);
         const u32 v = g * 4 + pr + 2 * h;
-        u64 res;
-        if constexpr (FASTQ) {
-          // (lo4 + hi4 * 2^32) mod q for q > 2^53: |lo4| < q already; hi4 * 2^32 through a quotient estimated
-          // in f64 (|hi4| < 2^52 is exact, the estimate is off by at most one) and two corrections
-          const u64 ah = (u64)(hi4 < 0 ? -hi4 : hi4), al = (u64)(lo4 < 0 ? -lo4 : lo4);
-          const u64 qhat = (u64)((double)ah * inv32);
-          long long rem = (long long)((ah << 32) - qhat * m.q);
-          if (rem < 0) rem += (long long)m.q;
-          if (rem >= (long long)m.q) rem -= (long long)m.q;
-          u64 rh = (u64)rem;
-          if (hi4 < 0 && rh) rh = m.q - rh;
-          const u64 rl = (lo4 < 0 && al) ? m.q - al : al;
-          res = addmod(rh, rl, m.q);
-        } else {
-          const __int128 tot = (__int128)lo4 + ((__int128)hi4 << 32);
-          u64 lo = (u64)tot, hi = (u64)((unsigned __int128)tot >> 64);
-          const bool neg = (long long)hi < 0;
-          if (neg) { lo = ~lo + 1; hi = ~hi + (lo == 0); }
-          res = reduce128(lo, hi, m);
-          if (neg && res) res = m.q - res;
-        }
         // intermediate [limb][slot][v][row]: the 32 lanes of a half write 32 consecutive rows of one vector
         if (row < sec.nrows && v < nv)
-          sec.tmp[vb * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res;
+          sec.tmp[vb * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res[pr];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Digit GEMM, wide form (more than 16 vectors): a workgroup of 8 waves computes 256 rows x 32 vectors of one
+// (limb, slot) -- wave (wr, wv) owns two row tiles and one batch of 16 vectors (8 accumulators) -- and BOTH operands
+// go through LDS: a raw tile is used by the two waves of its row pair, a digit tile by the four waves of its batch.
+// Per MFMA that is 256 bytes through L2 / L1 instead of the 512 of gemm_digits_kernel (128 rows x 16 vectors, raw
+// tiles straight to registers), and the ablations of round 2 (profiles/r02_gemm_ablations.txt) say the loads, not the
+// matrix pipe, set that kernel's time: no MFMA at all saves 8 % of it, no loads 36 %.
+// Staging is LDS-DMA (global_load_lds_dwordx4: one 1-KiB tile per wave-instruction, lane-linear in both memories --
+// XM and YD are stored as the MFMA fragments lie), four 32-KiB buffers of 2 j-blocks each; two stages stay in
+// flight across every barrier (counted s_waitcnt vmcnt + raw s_barrier: __syncthreads() would drain them):
+//     wait for my DMAs of stage s | barrier | issue the DMAs of stage s+3 | 16 MFMAs per wave on stage s
+// The epilogue is gemm_digits_kernel's (gemm_recombine, intermediate [limb][slot][v][row], gemm_finish).
+// Needs k % 16 == 0 (whole stages); the launcher falls back to gemm_digits_kernel otherwise and for <= 16 vectors.
+// ------------------------------------------------------------------------------------
+template <int ELL, bool FASTQ>
+__global__ __launch_bounds__(512, 2) void gemm_digits_wide_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
+                                                                   const Mod* __restrict__ mods, u32 k, u32 L, u32 nv_total,
+                                                                   u32 nv_pad, u32 vbn, size_t yd_b16) {
+  static_assert(PVW_GEMM_RPW == 1, "XM is padded to groups of four row tiles");
+  constexpr int CJ = 2;                                    // j-blocks per stage
+  constexpr int NB = 4;                                    // stage buffers: two stages stay in flight across every barrier
+  constexpr int RTW = 8, NG = 8;                           // row tiles / vector groups (of 4) per workgroup
+  constexpr int STAGE = (RTW + NG) * CJ * 64;              // 16-byte elements per stage: 32 KiB
+  constexpr int GPS = (RTW + NG) * CJ / 8;                 // LDS-DMA instructions per wave per stage: 4
+  __shared__ v4i32 stage[NB * STAGE];                      // ONE array (a second __shared__ object next to LDS-DMA
+                                                           // destinations makes hipcc drain the DMAs early)
+  const u32 JB = k / 4, NST = JB / CJ;
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 wr = wave >> 1, wv = wave & 1;
+  const u32 RTa = sa.rt_groups * 4, RTb = sb.rt_groups * 4;                  // row tiles of the two sections (padded)
+  const u32 ga = (RTa + RTW - 1) / RTW, gb = (RTb + RTW - 1) / RTW;          // workgroups along the rows
+  const u32 vbpn = (vbn + 1) / 2;                                            // pairs of 16-vector batches
+  u32 bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous (see gemm_digits_kernel)
+  const u32 vbp = bid % vbpn;
+  bid /= vbpn;
+  const u32 ls = bid / (ga + gb), rg = bid % (ga + gb);
+  const u32 limb = ls / ELL, slot = ls % ELL;
+  const bool in_a = rg < ga;
+  const GemmSection& sec = in_a ? sa : sb;
+  const u32 RT = in_a ? RTa : RTb;
+  const u32 rtbase = (in_a ? rg : rg - ga) * RTW;
+  const u32 rows_pad = sec.rt_groups * PVW_GEMM_ROWS_PER_WG;
+  // ---- what this wave stages: tiles GPS wave .. GPS wave + GPS - 1 of the 32 of a stage (waves 0-3 raw, 4-7 digits) ----
+  const v4i32* src[GPS];
+  {
+    const v4i32* xm = reinterpret_cast<const v4i32*>(sec.XM);
+    const v4i32* yd = reinterpret_cast<const v4i32*>(YD);
+#pragma unroll
+    for (int x = 0; x < GPS; ++x) {
+      const u32 t = wave * GPS + x, jb_i = t % CJ;
+      if (wave < 4) {
+        u32 rt = rtbase + t / CJ;
+        rt = rt < RT ? rt : RT - 1;                          // past the section: re-read its last tile (never stored)
+        src[x] = xm + ((((size_t)limb * ELL + slot) * RT + rt) * JB + jb_i) * 64 + lane;
+      } else {
+        const u32 g_i = (t - RTW * CJ) / CJ;                 // 0..7: batch (g_i >> 2) of the pair, group (g_i & 3)
+        u32 vbq = 2 * vbp + (g_i >> 2);
+        vbq = vbq < vbn ? vbq : vbn - 1;
+        src[x] = yd + (vbq * yd_b16) / 16 + (((((size_t)(g_i & 3)) * L + limb) * ELL + slot) * JB + jb_i) * 64 + lane;
+      }
+    }
+  }
+  auto issue = [&](u32 st) {
+    const u32 b = st % NB;
+#pragma unroll
+    for (int x = 0; x < GPS; ++x)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x] + (size_t)st * CJ * 64),
+                                       (__attribute__((address_space(3))) void*)&stage[b * STAGE + (wave * GPS + x) * 64], 16, 0, 0);
+  };
+  v16i32 acc[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[r][g] = (v16i32){};
+  issue(0);
+  if (NST > 1) issue(1);
+  if (NST > 2) issue(2);
+  for (u32 st = 0; st < NST; ++st) {
+    // this wave's DMAs of stage st have landed once at most the 2 younger stages' (2 * GPS instructions) are
+    // outstanding; the barrier extends that to every wave's and says that stage st - 1 has been consumed
+    const u32 ahead = NST - 1 - st;                          // stages issued after st (capped at 2)
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(GPS == 4, "the counted waits above assume four DMAs per wave and stage");
+    __builtin_amdgcn_s_barrier();
+    if (st + 3 < NST) issue(st + 3);                         // into the buffer stage st - 1 has just left
+    const v4i32* raw = &stage[(st % NB) * STAGE + (2 * wr) * CJ * 64 + lane];
+    const v4i32* dig = &stage[(st % NB) * STAGE + (RTW + 4 * wv) * CJ * 64 + lane];
+#pragma unroll
+    for (int jb_i = 0; jb_i < CJ; ++jb_i) {
+      v4i32 ra[2], dg[4];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) ra[r] = raw[(r * CJ + jb_i) * 64];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dg[g] = dig[(g * CJ + jb_i) * 64];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dg[g], ra[r], acc[r][g], 0, 0, 0);
+    }
+  }
+  // ---- epilogue ----
+  const Mod m = mods[limb];
+  const u32 h = lane >> 5, rr = lane & 31;
+  const double inv32 = 4294967296.0 / (double)m.q;
+  const u32 vb = 2 * vbp + wv;
+  if (vb >= vbn) return;
+  const u32 nv = (nv_total - 16 * vb) < 16 ? (nv_total - 16 * vb) : 16;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const u32 rt = rtbase + 2 * wr + r;
+    if (rt >= RT || rt * 32 >= sec.nrows) continue;          // wave-uniform
+    const u32 row = rt * 32 + rr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u64 res[2];
+      gemm_recombine<FASTQ>(acc[r][g], m, inv32, res);
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const u32 v = g * 4 + pr + 2 * h;
+        if (row < sec.nrows && v < nv)
+          sec.tmp[vb * sec.tmp_bstride + (((size_t)limb * ELL + slot) * nv_pad + v) * rows_pad + row] = res[pr];
       }
     }
   }
@@ -2937,6 +3077,15 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
     if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, true><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16)); } \
     else { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, false><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16)); } \
   } while (0)
+  // more than 16 vectors and whole stages of 16 terms: the wide form (256 rows x 32 vectors per workgroup, both
+  // operands through LDS).  PVW_GEMM_WIDE=0 in the tuning build selects gemm_digits_kernel everywhere.
+  const bool wide = vbn >= 2 && k % 16 == 0 && k >= 16 && PVW_ENV_INT("PVW_GEMM_WIDE", 1) != 0;
+  if (wide) {
+    const u32 ga = (sa.rt_groups * 4 + 7) / 8, gb2 = (sb.rt_groups * 4 + 7) / 8;
+    const u32 wblocks = (ga + gb2) * L * ell * ((vbn + 1) / 2);
+    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, true><<<dim3(wblocks), dim3(512), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); }
+    else { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, false><<<dim3(wblocks), dim3(512), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); }
+  } else {
   // fully unrolled chunk loops for the BASELINE geometries (k = 256: 8 chunks of 8 j-blocks, k = 512: 16), full vector groups
   static const int unroll_ok = (int)PVW_ENV_INT("PVW_GEMM_UNROLL", 1);
   if (NVG == 4 && unroll_ok && !(dbg & 1) && k == 256) { PVW_GEMM_LAUNCH(4, 8); }
@@ -2949,6 +3098,7 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
     default: return hipErrorInvalidValue;
   }
 #undef PVW_GEMM_LAUNCH
+  }
   if (sa.nrows) {
     PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sa.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
                               sa, t.mods, L, nv, nv_pad, sa.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_a, SY, sy_b16));
