@@ -2022,6 +2022,9 @@ __device__ __forceinline__ void transpose4x4_bytes(u32 x0, u32 x1, u32 x2, u32 x
   y2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
   y3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
+// digit GEMM with biased accumulators (gemm_recombine_biased): the geometries it is exact for
+constexpr u32 PVW_GEMM_BIASED_MAX_K = 512;               // |half| <= 8 k 2^14 (2^24 + 2^16 + 2^8 + 1) < 2^51
+__host__ __device__ inline bool gemm_biased(u32 k) { return k <= PVW_GEMM_BIASED_MAX_K; }
 template <int ELL, bool STAGE>
 __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ vhat, size_t vstride,
                                                          signed char* __restrict__ YD, int* __restrict__ SY,
@@ -2119,7 +2122,13 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
   }
   if (lane == 0) {
     const u64 r = reduce128(csum_lo, (u64)csum_hi, m);
-    reinterpret_cast<u64*>(SY + (((size_t)vg * L + limb) * ELL + slot) * 32)[v4] = mulmod(r, 128, m);
+    u64 corr = mulmod(r, 128, m);
+    if (gemm_biased(k)) {                                    // minus the constant the biased accumulators leave: 2^51 + 2^83
+      const u64 c51 = (1ull << 51) % m.q;
+      const u64 cb = addmod(c51, mulmod(c51, (1ull << 32) % m.q, m), m.q);
+      corr = corr >= cb ? corr - cb : corr + m.q - cb;
+    }
+    reinterpret_cast<u64*>(SY + (((size_t)vg * L + limb) * ELL + slot) * 32)[v4] = corr;
   }
 }
 
@@ -2130,6 +2139,51 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
 // ending up with the LOW halves (digits 0-3) of four vectors and the upper half with their HIGH halves (digits 4-7).
 // One exchange between the halves (v_permlane32_swap: upper half of one register <-> lower half of another) pairs
 // them up: the lower lanes finish vectors 0 and 1, the upper lanes vectors 2 and 3.
+//
+// BIASED (k <= PVW_GEMM_BIASED_MAX_K): the accumulators start at gemm_acc_init(), 2^27 in every digit-3 register, so a
+// lane's half-sum comes out as half + 2^51 in (0, 2^52) -- no signs -- and is formed exactly in f64 (4 conversions and
+// 3 fused multiply-adds; the integer form needs 13 two-dword shift/add instructions).  The finished sum carries the
+// constant 2^51 + 2^83, which vec_digits_kernel has taken out of the offset correction that gemm_finish adds.
+// FASTQ (every q wider than 54 bits): (lo' + hi' 2^32) mod q through a quotient estimate in f64 that is never above
+// the true quotient and at most one below it (inv32 = 2^32 / q (1 - 2^-40)), so x - qhat q lies in [0, 2q), plus
+// lo' < 2^52 in [0, 3q): two conditional subtractions.
+__device__ __forceinline__ v16i32 gemm_acc_init(bool biased) {
+  const int b = biased ? (1 << 27) : 0;
+  return (v16i32){0, 0, 0, b, 0, 0, 0, b, 0, 0, 0, b, 0, 0, 0, b};
+}
+__device__ __forceinline__ double gemm_inv32(const Mod& m, bool biased) {
+  const double inv = 4294967296.0 / (double)m.q;
+  return biased ? inv * (1.0 - 0x1p-40) : inv;
+}
+template <bool FASTQ>
+__device__ __forceinline__ void gemm_recombine_biased(const v16i32& a, const Mod& m, double inv32, u64 (&res)[2]) {
+  double half[4];
+#pragma unroll
+  for (int v4 = 0; v4 < 4; ++v4)
+    half[v4] = __builtin_fma((double)a[4 * v4 + 3], 0x1p24,
+                             __builtin_fma((double)a[4 * v4 + 2], 0x1p16, __builtin_fma((double)a[4 * v4 + 1], 0x1p8, (double)a[4 * v4])));
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const u64 P = (u64)__double_as_longlong(half[pr]), Q = (u64)__double_as_longlong(half[pr + 2]);
+    const auto slo = __builtin_amdgcn_permlane32_swap((u32)P, (u32)Q, false, false);
+    const auto shi = __builtin_amdgcn_permlane32_swap((u32)(P >> 32), (u32)(Q >> 32), false, false);
+    const double lo4 = __longlong_as_double((long long)(((u64)shi[0] << 32) | slo[0]));   // low half-sum + 2^51
+    const double hi4 = __longlong_as_double((long long)(((u64)shi[1] << 32) | slo[1]));   // high half-sum + 2^51
+    // an integer below 2^52 plus 2^52 has that integer as its mantissa
+    const u64 lo_i = (u64)__double_as_longlong(lo4 + 0x1p52) & 0x000fffffffffffffull;
+    const u64 hi_b = (u64)__double_as_longlong(hi4 + 0x1p52);
+    if constexpr (FASTQ) {
+      const u32 qhat = (u32)(hi4 * inv32);                                     // < 2^30
+      u64 s = ((u64)(u32)hi_b << 32) - (u64)qhat * m.q + lo_i;                 // mod 2^64; the true value is in [0, 3q)
+      if (s >= 2 * m.q) s -= 2 * m.q;
+      if (s >= m.q) s -= m.q;
+      res[pr] = s;
+    } else {
+      const unsigned __int128 tot = (unsigned __int128)lo_i + ((unsigned __int128)(hi_b & 0x000fffffffffffffull) << 32);
+      res[pr] = reduce128((u64)tot, (u64)(tot >> 64), m);
+    }
+  }
+}
 template <bool FASTQ>
 __device__ __forceinline__ void gemm_recombine(const v16i32& a, const Mod& m, double inv32, u64 (&res)[2]) {
   long long half[4];                                     // this lane's half-sum of the four vectors, |.| < 2^51
@@ -2185,7 +2239,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
                                                            size_t yd_b16, size_t sy_b16) {
   const u32 dbg = PVW_TUNING ? dbg_arg : 0;                // the shipped build has no timing branches
   // dbg (tuning build: PVW_GEMM_DEBUG, timing experiments only, results wrong): 1 = no K loop, 2 = no epilogue;
-  // compile-time ablations -DPVW_GEMM_ABLATE=bits: 8 = no A loads, 16 = no B loads, 32 = no MFMA
+  // compile-time ablations -DPVW_GEMM_ABLATE=bits: 8 = no A loads, 16 = no B loads, 32 = no MFMA, 64 = no epilogue (wide form)
   // block = (limb, slot, group of 4*RPW row tiles); the 4 waves share the vector-digit tiles through
   // LDS (CJ j-blocks at a time); each wave owns RPW row tiles of 32 rows and streams their raw u64 tiles.
   constexpr int CJ = 8;                                    // j-blocks per staged chunk (32 MFMAs per wave per barrier)
@@ -2193,6 +2247,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
   __shared__ v4i32 bl[2][NVG * CJ * 64];                   // two chunks of NVG*CJ KiB
   // NCH != 0: the launcher guarantees k == 4 * NCH * CJ, so every bounds test below folds away
   const u32 JB = NCH ? (u32)(NCH * CJ) : ((dbg & 1) ? 0 : (k + 3) / 4);
+  const bool biased = gemm_biased(k);                      // uniform: see gemm_recombine_biased
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 rtg_total = sa.rt_groups + sb.rt_groups;
   // XCD-aware order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of
@@ -2225,7 +2280,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 #pragma unroll
   for (int r = 0; r < RPW; ++r)
 #pragma unroll
-    for (int g = 0; g < NVG; ++g) acc[r][g] = (v16i32){};
+    for (int g = 0; g < NVG; ++g) acc[r][g] = gemm_acc_init(biased);
   const v4i32 zero4 = (v4i32){0, 0, 0, 0};
   // software pipeline over chunks of CJ j-blocks: the A tiles and this thread's share of the B tiles
   // of chunk c+1 are in flight (registers) while chunk c is multiplied out of LDS
@@ -2319,7 +2374,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
   // recombine (gemm_recombine): out[row][v] = sum_b C[(v, b)][row] 2^(8b) mod q; the offset correction is added by gemm_finish
   const Mod m = mods[limb];
   const u32 h = lane >> 5, rr = lane & 31;
-  const double inv32 = 4294967296.0 / (double)m.q;           // FASTQ: every modulus is wider than 54 bits
+  const double inv32 = gemm_inv32(m, biased);                // FASTQ: every modulus is wider than 54 bits
   if (dbg & 2) {
     int keep = 0;
 #pragma unroll
@@ -2338,7 +2393,8 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 #pragma unroll
     for (int g = 0; g < NVG; ++g) {
       u64 res[2];
-      gemm_recombine<FASTQ>(acc[r][g], m, inv32, res);
+      if (biased) gemm_recombine_biased<FASTQ>(acc[r][g], m, inv32, res);
+      else gemm_recombine<FASTQ>(acc[r][g], m, inv32, res);
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         const u32 v = g * 4 + pr + 2 * h;
@@ -2360,23 +2416,29 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 // Staging is LDS-DMA (global_load_lds_dwordx4: one 1-KiB tile per wave-instruction, lane-linear in both memories --
 // XM and YD are stored as the MFMA fragments lie), four 32-KiB buffers of 2 j-blocks each; two stages stay in
 // flight across every barrier (counted s_waitcnt vmcnt + raw s_barrier: __syncthreads() would drain them):
-//     wait for my DMAs of stage s | barrier | issue the DMAs of stage s+3 | 16 MFMAs per wave on stage s
+//     wait for my DMAs of stage s+1 | barrier | issue the DMAs of stage s+3 | 16 MFMAs per wave on stage s, the
+//     fragment reads of the next j-block (of stage s or s+1) issued ahead of each group of 8
 // The epilogue is gemm_digits_kernel's (gemm_recombine, intermediate [limb][slot][v][row], gemm_finish).
 // Needs k % 16 == 0 (whole stages); the launcher falls back to gemm_digits_kernel otherwise and for <= 16 vectors.
 // ------------------------------------------------------------------------------------
-template <int ELL, bool FASTQ>
-__global__ __launch_bounds__(512, 2) void gemm_digits_wide_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
-                                                                   const Mod* __restrict__ mods, u32 k, u32 L, u32 nv_total,
-                                                                   u32 nv_pad, u32 vbn, size_t yd_b16) {
+template <int ELL, bool FASTQ, int WRN>
+__global__ __launch_bounds__(128 * WRN, 2) void gemm_digits_wide_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
+                                                                         const Mod* __restrict__ mods, u32 k, u32 L, u32 nv_total,
+                                                                         u32 nv_pad, u32 vbn, size_t yd_b16) {
   static_assert(PVW_GEMM_RPW == 1, "XM is padded to groups of four row tiles");
+  static_assert(WRN == 2 || WRN == 4, "4 or 8 waves");
+  constexpr int NWV = 2 * WRN;                             // waves: WRN along the rows x 2 batches of 16 vectors
   constexpr int CJ = 2;                                    // j-blocks per stage
-  constexpr int NB = 4;                                    // stage buffers: two stages stay in flight across every barrier
-  constexpr int RTW = 8, NG = 8;                           // row tiles / vector groups (of 4) per workgroup
-  constexpr int STAGE = (RTW + NG) * CJ * 64;              // 16-byte elements per stage: 32 KiB
-  constexpr int GPS = (RTW + NG) * CJ / 8;                 // LDS-DMA instructions per wave per stage: 4
+  constexpr int NB = WRN == 4 ? 4 : 3;                     // stage buffers (8 waves: 128 KiB, one workgroup per CU; 4 waves: 72 KiB, two)
+  constexpr int AHEAD = NB - 2;                            // stages still in flight when a barrier is passed
+  constexpr bool CROSS = WRN == 4;                         // the barrier of iteration s certifies stage s + 1 (else stage s)
+  constexpr int RTW = 2 * WRN, NG = 8;                     // row tiles / vector groups (of 4) per workgroup
+  constexpr int STAGE = (RTW + NG) * CJ * 64;              // 16-byte elements per stage: 32 / 24 KiB
+  constexpr int GPS = (RTW + NG) * CJ / NWV;               // LDS-DMA instructions per wave per stage: 4 / 6
   __shared__ v4i32 stage[NB * STAGE];                      // ONE array (a second __shared__ object next to LDS-DMA
                                                            // destinations makes hipcc drain the DMAs early)
   const u32 JB = k / 4, NST = JB / CJ;
+  const bool biased = gemm_biased(k);                      // uniform: see gemm_recombine_biased
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 wr = wave >> 1, wv = wave & 1;
   const u32 RTa = sa.rt_groups * 4, RTb = sb.rt_groups * 4;                  // row tiles of the two sections (padded)
@@ -2393,7 +2455,7 @@ __global__ __launch_bounds__(512, 2) void gemm_digits_wide_kernel(GemmSection sa
   const u32 RT = in_a ? RTa : RTb;
   const u32 rtbase = (in_a ? rg : rg - ga) * RTW;
   const u32 rows_pad = sec.rt_groups * PVW_GEMM_ROWS_PER_WG;
-  // ---- what this wave stages: tiles GPS wave .. GPS wave + GPS - 1 of the 32 of a stage (waves 0-3 raw, 4-7 digits) ----
+  // ---- what this wave stages: tiles GPS wave .. GPS wave + GPS - 1 of a stage's (RTW raw + NG digit tiles) x CJ ----
   const v4i32* src[GPS];
   {
     const v4i32* xm = reinterpret_cast<const v4i32*>(sec.XM);
@@ -2401,20 +2463,19 @@ __global__ __launch_bounds__(512, 2) void gemm_digits_wide_kernel(GemmSection sa
 #pragma unroll
     for (int x = 0; x < GPS; ++x) {
       const u32 t = wave * GPS + x, jb_i = t % CJ;
-      if (wave < 4) {
-        u32 rt = rtbase + t / CJ;
-        rt = rt < RT ? rt : RT - 1;                          // past the section: re-read its last tile (never stored)
-        src[x] = xm + ((((size_t)limb * ELL + slot) * RT + rt) * JB + jb_i) * 64 + lane;
-      } else {
-        const u32 g_i = (t - RTW * CJ) / CJ;                 // 0..7: batch (g_i >> 2) of the pair, group (g_i & 3)
-        u32 vbq = 2 * vbp + (g_i >> 2);
-        vbq = vbq < vbn ? vbq : vbn - 1;
-        src[x] = yd + (vbq * yd_b16) / 16 + (((((size_t)(g_i & 3)) * L + limb) * ELL + slot) * JB + jb_i) * 64 + lane;
-      }
+      u32 rt = rtbase + t / CJ;
+      rt = rt < RT ? rt : RT - 1;                            // past the section: re-read its last tile (never stored)
+      const v4i32* sraw = xm + ((((size_t)limb * ELL + slot) * RT + rt) * JB + jb_i) * 64 + lane;
+      const u32 g_i = (t >= RTW * CJ ? t - RTW * CJ : 0) / CJ;   // 0..7: batch (g_i >> 2) of the pair, group (g_i & 3)
+      u32 vbq = 2 * vbp + (g_i >> 2);
+      vbq = vbq < vbn ? vbq : vbn - 1;
+      const v4i32* sdig = yd + (vbq * yd_b16) / 16 + (((((size_t)(g_i & 3)) * L + limb) * ELL + slot) * JB + jb_i) * 64 + lane;
+      src[x] = t < RTW * CJ ? sraw : sdig;
     }
   }
   auto issue = [&](u32 st) {
     const u32 b = st % NB;
+    if (PVW_ABL(24)) return;                                 // timing experiment: nothing staged
 #pragma unroll
     for (int x = 0; x < GPS; ++x)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x] + (size_t)st * CJ * 64),
@@ -2424,39 +2485,89 @@ __global__ __launch_bounds__(512, 2) void gemm_digits_wide_kernel(GemmSection sa
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[r][g] = (v16i32){};
-  issue(0);
-  if (NST > 1) issue(1);
-  if (NST > 2) issue(2);
-  for (u32 st = 0; st < NST; ++st) {
-    // this wave's DMAs of stage st have landed once at most the 2 younger stages' (2 * GPS instructions) are
-    // outstanding; the barrier extends that to every wave's and says that stage st - 1 has been consumed
-    const u32 ahead = NST - 1 - st;                          // stages issued after st (capped at 2)
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    static_assert(GPS == 4, "the counted waits above assume four DMAs per wave and stage");
-    __builtin_amdgcn_s_barrier();
-    if (st + 3 < NST) issue(st + 3);                         // into the buffer stage st - 1 has just left
+    for (int g = 0; g < 4; ++g) acc[r][g] = gemm_acc_init(biased);
+  // Fragment reads and MFMAs must overlap (per stage a wave reads 12 KiB for its 16 MFMAs): two fragment sets, the
+  // reads of j-block i+1 issued under the MFMAs of j-block i.  The 8-wave form (all of a SIMD's waves in one
+  // workgroup, in step) carries that across the stage boundary: the barrier of iteration s certifies stage s + 1.
+  // The 4-wave form leaves the first read of a stage exposed -- the other workgroup on the CU fills the gap.
+  v4i32 f0[6], f1[6];                                        // [0..1] raw tiles of the two row tiles, [2..5] digit tiles
+  auto read = [&](v4i32 (&f)[6], u32 st, int jb_i) {
     const v4i32* raw = &stage[(st % NB) * STAGE + (2 * wr) * CJ * 64 + lane];
     const v4i32* dig = &stage[(st % NB) * STAGE + (RTW + 4 * wv) * CJ * 64 + lane];
 #pragma unroll
-    for (int jb_i = 0; jb_i < CJ; ++jb_i) {
-      v4i32 ra[2], dg[4];
+    for (int r = 0; r < 2; ++r) f[r] = raw[(r * CJ + jb_i) * 64];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) ra[r] = raw[(r * CJ + jb_i) * 64];
+    for (int g = 0; g < 4; ++g) f[2 + g] = dig[(g * CJ + jb_i) * 64];
+  };
+  // 8 MFMAs on one fragment set.  Everything else a wave has to issue rides in the gaps between them, a little per
+  // gap (MI355X_MICROARCH.md, LDS: two ds_read_b128 per gap are free, a third per wave saturates the LDS array and the
+  // MFMA behind it waits for the ISSUE of the reads; an LDS-DMA instruction costs 25-60 cycles in a quiet gap, 100+
+  // next to a burst of reads): the six fragment reads into the OTHER set behind MFMAs 1-3 (not earlier: hipcc puts a
+  // full lgkmcnt(0) before a set's first use), this wave's DMAs for stage st + NB - 1 behind MFMAs 4 onwards.
+  auto issue_one = [&](u32 st, int x) {
+    if (PVW_ABL(24)) return;                                 // timing experiment: nothing staged
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[x] + (size_t)st * CJ * 64),
+                                     (__attribute__((address_space(3))) void*)&stage[(st % NB) * STAGE + (wave * GPS + x) * 64], 16, 0, 0);
+  };
+  auto mac_and_read = [&](const v4i32 (&f)[6], v4i32 (&fn)[6], u32 st_n, int jb_n, bool rd, u32 st_dma, bool dma, int x0) {
+    const v4i32* raw = &stage[(st_n % NB) * STAGE + (2 * wr) * CJ * 64 + lane];
+    const v4i32* dig = &stage[(st_n % NB) * STAGE + (RTW + 4 * wv) * CJ * 64 + lane];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) dg[g] = dig[(g * CJ + jb_i) * 64];
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(dg[g], ra[r], acc[r][g], 0, 0, 0);
+    for (int i = 0; i < 8; ++i) {
+      const int r = i >> 2, g = i & 3;
+      if (PVW_ABL(32)) acc[r][g][0] += f[2 + g][0] ^ f[r][0];   // timing experiment: no MFMA
+      else acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[2 + g], f[r], acc[r][g], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (rd && i == 0 && !PVW_ABL(256)) { fn[0] = raw[(0 * CJ + jb_n) * 64]; fn[1] = raw[(1 * CJ + jb_n) * 64]; }
+      if (rd && i == 1 && !PVW_ABL(256)) { fn[2] = dig[(0 * CJ + jb_n) * 64]; fn[3] = dig[(1 * CJ + jb_n) * 64]; }
+      if (rd && i == 2 && !PVW_ABL(256)) { fn[4] = dig[(2 * CJ + jb_n) * 64]; fn[5] = dig[(3 * CJ + jb_n) * 64]; }
+      if (dma && i >= 3 && i - 3 < GPS / 2) issue_one(st_dma, x0 + i - 3);
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  // s_waitcnt vmcnt(n stages x GPS): the immediate must be a literal
+  auto wait_stages = [&](u32 n) {
+    if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GPS) : "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  static_assert(GPS % 2 == 0 && GPS / 2 <= 5 && CJ == 2 && AHEAD <= 2, "two j-blocks per stage; wait_stages knows 0, 1 and 2 stages");
+#pragma unroll
+  for (int i = 0; i < NB - 1; ++i)
+    if ((u32)i < NST) issue(i);
+  if constexpr (CROSS) {
+    wait_stages(NST - 1 < (u32)(NB - 2) ? NST - 1 : (u32)(NB - 2));    // stage 0 has landed (mine; the barrier: everyone's)
+    __builtin_amdgcn_s_barrier();
+    read(f0, 0, 0);
+  }
+  for (u32 st = 0; st < NST; ++st) {
+    // CROSS: my DMAs of stage st + 1 (else: of stage st) have landed once only the AHEAD younger stages' are outstanding;
+    // the barrier extends that to every wave's and says that every wave has consumed stage st - 1
+    const u32 newest = st + NB - 2 < NST - 1 ? st + NB - 2 : NST - 1;   // newest stage issued so far
+    const u32 need = CROSS ? st + 1 : st;
+    wait_stages(newest > need ? newest - need : 0);
+    if (!PVW_ABL(128)) __builtin_amdgcn_s_barrier();          // (128, 256: timing experiments -- no barrier, no fragment reads)
+    const bool dma = st + NB - 1 < NST;                       // into the buffer stage st - 1 has just left
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!CROSS) read(f0, st, 0);
+    mac_and_read(f0, f1, st, 1, true, st + NB - 1, dma, 0);
+    mac_and_read(f1, f0, st + 1 < NST ? st + 1 : st, 0, CROSS, st + NB - 1, dma, GPS / 2);   // past the end: a harmless re-read
+  }
+  if (PVW_ABL(64)) {                                         // timing experiment: no epilogue
+    int keep = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) keep ^= acc[r][g][tt];
+    if (keep == 0x7fffffff && k == 0xffffffffu) sec.tmp[0] = 1;
+    return;
   }
   // ---- epilogue ----
   const Mod m = mods[limb];
   const u32 h = lane >> 5, rr = lane & 31;
-  const double inv32 = 4294967296.0 / (double)m.q;
+  const double inv32 = gemm_inv32(m, biased);
   const u32 vb = 2 * vbp + wv;
   if (vb >= vbn) return;
   const u32 nv = (nv_total - 16 * vb) < 16 ? (nv_total - 16 * vb) : 16;
@@ -2468,7 +2579,8 @@ __global__ __launch_bounds__(512, 2) void gemm_digits_wide_kernel(GemmSection sa
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       u64 res[2];
-      gemm_recombine<FASTQ>(acc[r][g], m, inv32, res);
+      if (biased) gemm_recombine_biased<FASTQ>(acc[r][g], m, inv32, res);
+      else gemm_recombine<FASTQ>(acc[r][g], m, inv32, res);
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         const u32 v = g * 4 + pr + 2 * h;
@@ -3081,10 +3193,21 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   // operands through LDS).  PVW_GEMM_WIDE=0 in the tuning build selects gemm_digits_kernel everywhere.
   const bool wide = vbn >= 2 && k % 16 == 0 && k >= 16 && PVW_ENV_INT("PVW_GEMM_WIDE", 1) != 0;
   if (wide) {
-    const u32 ga = (sa.rt_groups * 4 + 7) / 8, gb2 = (sb.rt_groups * 4 + 7) / 8;
-    const u32 wblocks = (ga + gb2) * L * ell * ((vbn + 1) / 2);
-    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, true><<<dim3(wblocks), dim3(512), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); }
-    else { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, false><<<dim3(wblocks), dim3(512), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); }
+    // 4 waves (128 rows x 32 vectors, two workgroups per CU: one's epilogue under the other's MFMAs) or 8 waves (256 x 32)
+    [[maybe_unused]] const int wform = (int)PVW_ENV_INT("PVW_GEMM_WIDE", 2);
+#define PVW_GEMM_WIDE_LAUNCH(WRN)                                                                                          \
+  do {                                                                                                                    \
+    const u32 ga = (sa.rt_groups * 4 + 2 * WRN - 1) / (2 * WRN), gb2 = (sb.rt_groups * 4 + 2 * WRN - 1) / (2 * WRN);       \
+    const u32 wblocks = (ga + gb2) * L * ell * ((vbn + 1) / 2);                                                           \
+    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, true, WRN><<<dim3(wblocks), dim3(128 * WRN), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); } \
+    else { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, false, WRN><<<dim3(wblocks), dim3(128 * WRN), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); } \
+  } while (0)
+#if PVW_TUNING
+    if (wform == 1) PVW_GEMM_WIDE_LAUNCH(4);
+    else
+#endif
+      PVW_GEMM_WIDE_LAUNCH(2);
+#undef PVW_GEMM_WIDE_LAUNCH
   } else {
   // fully unrolled chunk loops for the BASELINE geometries (k = 256: 8 chunks of 8 j-blocks, k = 512: 16), full vector groups
   static const int unroll_ok = (int)PVW_ENV_INT("PVW_GEMM_UNROLL", 1);

@@ -13,7 +13,7 @@ for p in ("p1", "p2"):
     f = glob.glob(f"gpurun_out/pmc_gemm/{p}/**/*_counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "gemm_digits_kernel" in r["Kernel_Name"]:
+        if "gemm_digits" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         print(p, k, "avg per launch %.4g" % (sum(v) / len(v)), "launches", len(v))
