@@ -1880,7 +1880,8 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
   const size_t b_api = al((size_t)k * k * P * 8);
   const size_t b_yd = al(yd_bytes(16 * nb, k, L, l)), b_sy = al(sy_bytes(16 * nb, L, l));   // whole batches: the last one is read in full
   const size_t b_small = al((size_t)2 * chunk * k * l * 8);                     // sk | ek of one chunk; two of these (double buffer)
-  const size_t b_rows = al((size_t)chunk * k * P * 8);                // s-hat rows | e rows, API layout [p][j or col][P]
+  const bool direct = l <= 32;                                        // see the chunk loop
+  const size_t b_rows = direct ? 0 : al((size_t)chunk * k * P * 8);   // l = 64 only: s-hat rows | e rows, API layout [p][j or col][P]
   const size_t b_xm = al(xm_words(chunk, k, L, l) * 8);
   const size_t b_tmp = al((size_t)nb * gemm_tmp_words(chunk, L, l) * 8);
   PVW_TRY(ws_scratch(w, b_api + b_yd + b_sy + 2 * b_small + 2 * b_rows + b_xm + b_tmp));
@@ -1893,9 +1894,10 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
   u64* d_erow = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + b_rows);
   u64* d_xm = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + 2 * b_rows);
   u64* d_tmp = (u64*)(base + b_api + b_yd + b_sy + 2 * b_small + 2 * b_rows + b_xm);
-  // everything derived from the secret keys: their coefficients (and explicit key errors), NTT(s) rows, the
-  // sampled / transformed errors and the MFMA-tiled copy of NTT(s) -- cleared by pvw_keygen when the call ends
-  ws_mark_secret(w, d_small2[0], 2 * b_small + 2 * b_rows + b_xm);
+  // everything derived from the secret keys: their coefficients (and explicit key errors), the MFMA-tiled copy of
+  // NTT(s), the GEMM intermediate (s A without the error) and, for l = 64, the rows of NTT(s) and of the transformed
+  // errors -- cleared by pvw_keygen when the call ends
+  ws_mark_secret(w, d_small2[0], 2 * b_small + 2 * b_rows + b_xm + b_tmp);
   // the secret keys of chunk i+1 are uploaded on a helper stream while chunk i computes
   const u32 nchunks = (b - a + chunk - 1) / chunk;
   if (!w->aux) PVW_HIP(hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking));
@@ -1922,31 +1924,44 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
     i64* d_small = d_small2[ci & 1];
     if (ci > 0) PVW_HIP(hipStreamWaitEvent(s, w->events[2 * ci], 0));          // this chunk's keys have arrived
     ProfScope ps(c, "keygen", s);
-    // one prologue launch: s-hat_p (secret_key.rs:98-112) and e_p (public_key.rs:128-132) as rows [p][.][limb][slot]
-    PrologueBatch pb{};
-    if (seed) pb.key[0] = make_key(seed);
-    PrologueJob& js = pb.job[0];
-    PrologueJob& je = pb.job[1];
-    js.sj.count = k; js.explicit_coeffs = d_small; js.rep_coeffs = (size_t)k * l;
-    js.out = d_srow; js.stride_poly = P; js.stride_limb = l; js.rep_out = (size_t)k * P;
-    je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = p0 * k; je.sj.count = k; je.sj.bound = c->b1;
-    je.rep_index0 = k;
-    if (ek) { je.explicit_coeffs = d_small + (size_t)chunk * k * l; je.rep_coeffs = (size_t)k * l; }
-    je.out = d_erow; je.stride_poly = P; je.stride_limb = l; je.rep_out = (size_t)k * P;
-    pb.njobs = 2;
-    pb.reps = cnt;
-    PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
-    PVW_HIP(hipEventRecord(w->events[2 * ci + 1], s));                         // this chunk's key buffer is free again
-    // the chunk's s-hat rows -> MFMA-tiled raw operand (the kernel writes the padding itself for l <= 32)
-    if (l > 32) PVW_HIP(hipMemsetAsync(d_xm, 0, xm_words(cnt, k, L, l) * 8, s));
-    PVW_HIP(launch_mftile(d_srow, false, d_xm, cnt, k, L, l, s));
-    // all k columns in one launch (crs.rs:152-168); out / addend element (v = col, row = p) at p * k * P + col * P
+    // l <= 32: s-hat_p (secret_key.rs:98-112) goes straight from the uploaded coefficients into the MFMA-tiled raw
+    // operand and the key errors e_p (public_key.rs:128-132) are drawn (or read) by the finish pass of the GEMM --
+    // no transformed rows of either in memory.  l = 64: both through API-layout rows from one prologue launch.
     GemmSection ga{d_xm, d_erow, d_erow, d_tmp, cnt, 0, 0}, gb{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     ga.tiled_out = c->dB;
     ga.tiled_row0 = p0 - c->party_lo;
     ga.tiled_swap = 1;
     ga.row_stride = (size_t)k * P;
-    PVW_HIP(launch_gemm_digits(ga, gb, d_yd, d_sy, c->dt, k, L, l, k, P, 0, s));
+    if (direct) {
+      PVW_HIP(launch_shat_mftile(d_small, d_xm, cnt, k, L, l, c->dt, s));
+      GemmErrSource es{};
+      if (ek) es.explicit_coeffs = d_small + (size_t)chunk * k * l;
+      else es.key = make_key(seed);
+      es.domain = DOM_EKEY; es.index0 = p0 * k; es.index_row = k; es.bound = c->b1;
+      ga.addend = nullptr;
+      ga.out = nullptr;
+      // all k columns in one launch (crs.rs:152-168)
+      PVW_HIP(launch_gemm_digits(ga, gb, d_yd, d_sy, c->dt, k, L, l, k, P, 0, s, &es));
+    } else {
+      PrologueBatch pb{};
+      if (seed) pb.key[0] = make_key(seed);
+      PrologueJob& js = pb.job[0];
+      PrologueJob& je = pb.job[1];
+      js.sj.count = k; js.explicit_coeffs = d_small; js.rep_coeffs = (size_t)k * l;
+      js.out = d_srow; js.stride_poly = P; js.stride_limb = l; js.rep_out = (size_t)k * P;
+      je.sj.kind = SAMPLE_UNIFORM; je.sj.domain = DOM_EKEY; je.sj.index0 = p0 * k; je.sj.count = k; je.sj.bound = c->b1;
+      je.rep_index0 = k;
+      if (ek) { je.explicit_coeffs = d_small + (size_t)chunk * k * l; je.rep_coeffs = (size_t)k * l; }
+      je.out = d_erow; je.stride_poly = P; je.stride_limb = l; je.rep_out = (size_t)k * P;
+      pb.njobs = 2;
+      pb.reps = cnt;
+      PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
+      PVW_HIP(hipMemsetAsync(d_xm, 0, xm_words(cnt, k, L, l) * 8, s));
+      PVW_HIP(launch_mftile(d_srow, false, d_xm, cnt, k, L, l, s));
+      // out / addend element (v = col, row = p) at p * k * P + col * P
+      PVW_HIP(launch_gemm_digits(ga, gb, d_yd, d_sy, c->dt, k, L, l, k, P, 0, s));
+    }
+    PVW_HIP(hipEventRecord(w->events[2 * ci + 1], s));                         // this chunk's key buffer is free again
     if (ci + 1 < nchunks) {
       // issued after this chunk's launches so that the host-side staging of a pageable copy overlaps the GPU's work;
       // the buffer of chunk i+1 was last read by the prologue of chunk i-1
@@ -2037,7 +2052,10 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
     // tiles and column sums (matrix-core form) or the s-hat vectors in w->rhat (VALU form).  d_row holds e only
     // until the product is added onto it, then rows of the public key.
     ws_mark_secret(w, d_small, b_small);
-    if (use_gemm) ws_mark_secret(w, d_vh, b_vh + b_yd + b_sy);
+    if (use_gemm) {
+      ws_mark_secret(w, d_tmp, b_tmp);                       // s A^T without the error
+      ws_mark_secret(w, d_vh, b_vh + b_yd + b_sy);
+    }
     else ws_mark_secret(w, w->rhat, w->rhat_bytes);
     // A -> API layout -> transpose polynomials (A^T[c][j] = A[j][c]) -> tiled / MFMA-tiled
     bool okk = launch_untile(c->dA, d_api, k, 0, k, L, l, false, c->dt, s) == hipSuccess;

@@ -175,15 +175,25 @@ inline size_t xm_words(u32 rows, u32 k, u32 L, u32 ell) {
 inline size_t yd_bytes(u32 nv, u32 k, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) * L * ell * ((k + 3) / 4) * 1024; }
 inline size_t sy_bytes(u32 nv, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) * L * ell * 32 * sizeof(int); }
 hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s);
+// small coefficients [row][j][l] -> NTT -> MFMA-tiled raw operand in one pass (l <= 32); padding included
+hipError_t launch_shat_mftile(const i64* coeffs, u64* XM, u32 rows, u32 k, u32 L, u32 ell, const DevTables& t, hipStream_t s);
 // element j of vector v at (limb, slot): vhat[v * vstride + limb * lstride + j * jstride + slot];
 // lstride = jstride = 0 selects the r-hat layout [limb][j][slot] (lstride = k * l, jstride = l)
 hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
                              const DevTables& t, hipStream_t s, size_t lstride = 0, size_t jstride = 0);
 // nv may exceed 16: batches of 16 vectors then run as extra workgroups of ONE launch (adjacent in dispatch
 // order, so they share the streamed matrix tiles through L2); tmp must hold ceil(nv/16) batches.
+// es != NULL (key generation; section a with tiled_out + tiled_swap, no section b, l <= 32): the finish pass adds
+// the key errors it draws or reads itself (GemmErrSource) instead of an addend from memory.
+struct GemmErrSource {
+  const i64* explicit_coeffs;   // [row][nv][l] small coefficients, or NULL: drawn uniformly in [-bound, bound]
+  ChaChaKey key;
+  u32 domain, index0, index_row;   // ChaCha stream of (row, v): index0 + row * index_row + v
+  u64 bound;
+};
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
-                              hipStream_t s);
+                              hipStream_t s, const GemmErrSource* es = nullptr);
 // read-only probe: every wave streams `tiles` consecutive 1-KiB tiles (16 in flight), grid as mac_rows
 #if PVW_TUNING
 // time stamps (100 MHz ticks, [2b] start / [2b+1] end) and HW_ID words of the workgroups of the last stamped mac_rows launch

@@ -2006,6 +2006,56 @@ __global__ __launch_bounds__(256) void mftile_rows_kernel(const u64* __restrict_
   }
 }
 
+// small coefficients [row][j][l] (secret keys: secret_key.rs:98-112) -> reduced, transformed and written straight
+// into the MFMA-tiled raw operand XM -- the prologue + mftile_rows pair of key generation in one pass, without the
+// API-layout rows in between.  One block = (32 rows, NJ = 4 JBG consecutive j, every gridDim.z-th limb): a thread
+// keeps ONE polynomial's coefficients in registers and per limb transforms them into an LDS image of the l x JBG
+// tiles (two images in turn: one barrier per limb), which leave as whole 1-KiB tiles.  Padding rows / j are written
+// as the offset-zero byte pattern, as mftile_rows_kernel does.
+template <int ELL>
+__global__ __launch_bounds__(256) void shat_mftile_kernel(const i64* __restrict__ coeffs, u64* __restrict__ XM, u32 rows, u32 k, u32 L, DevTables t) {
+  constexpr int JBG = 2, NJ = 4 * JBG;                          // 32 rows x 8 j = 256 polynomials: one per thread
+  constexpr int PLANE = JBG * 128 + 2;                          // u64 per slot plane of the tile image (+2: bank spread)
+  __shared__ u64 lt[2][ELL * PLANE];
+  const u32 JB = (k + 3) / 4, jg = blockIdx.x, rt = blockIdx.y, RT = gridDim.y;
+  const u32 row = threadIdx.x & 31, jj = threadIdx.x >> 5;       // consecutive lanes: consecutive rows of one j
+  const u32 grow = rt * 32 + row, gj = jg * NJ + jj;
+  i64 c[ELL];
+  if (grow < rows && gj < k) {
+    const v2u64* src = reinterpret_cast<const v2u64*>(coeffs + ((size_t)grow * k + gj) * ELL);
+#pragma unroll
+    for (int sl = 0; sl < ELL; sl += 2) {
+      const v2u64 v = src[sl / 2];
+      c[sl] = (i64)v.x;
+      c[sl + 1] = (i64)v.y;
+    }
+  } else {
+#pragma unroll
+    for (int sl = 0; sl < ELL; ++sl) c[sl] = 0;
+  }
+  const u32 w = ((jj >> 2) * 64 + ((jj >> 1) & 1) * 32 + row) * 2 + (jj & 1);
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  u32 buf = 0;
+  for (u32 limb = blockIdx.z; limb < L; limb += gridDim.z, buf ^= 1) {
+    const Mod m = t.mods[limb];
+    u64 a[ELL];
+#pragma unroll
+    for (int sl = 0; sl < ELL; ++sl) a[sl] = signed_residue(c[sl], m);
+    ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, m);
+#pragma unroll
+    for (int sl = 0; sl < ELL; ++sl) lt[buf][sl * PLANE + w] = a[sl] ^ 0x8080808080808080ULL;   // bytes stored signed-offset, as mftile_kernel does
+    __syncthreads();       // image `buf` is complete.  It is next written two limbs on, by waves that have passed the
+                           // barrier in between, which every wave reaches only after the reads below
+    for (u32 tq = wave; tq < ELL * JBG; tq += 4) {
+      const u32 slot = tq / JBG, jbl = tq % JBG;
+      if (jg * JBG + jbl >= JB) continue;
+      const v2u64 v = (v2u64){lt[buf][slot * PLANE + (jbl * 64 + lane) * 2], lt[buf][slot * PLANE + (jbl * 64 + lane) * 2 + 1]};
+      const size_t tile = (((size_t)limb * ELL + slot) * RT + rt) * JB + (jg * JBG + jbl);
+      *reinterpret_cast<v2u64*>(XM + tile * 128 + lane * 2) = v;
+    }
+  }
+}
+
 // vector elements -> digit tiles YD[vg][limb][slot][jb][h*32+col][16] and the offset correction SY.
 // One wave per (v, limb, slot); lane = j-block: each lane turns 4 consecutive j into the 8 shifted
 // copies y*2^(8a) mod q and writes their balanced digits as 16 16-byte runs.
@@ -2666,6 +2716,70 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
     }
 }
 
+// gemm_finish for key generation with the key errors made on the spot: b_p[col] = (s_p A)[col] + e_p[col]
+// (public_key.rs:128-147), e_p[col] either drawn here (the ChaCha stream and rejection sampler of the prologue:
+// uniform in [-bound, bound], stream index0 + p * index_row + col) or read as explicit coefficients [p][col][l]; no
+// transformed error rows in memory, no prologue launch.  One THREAD = (party, column): it makes the polynomial's
+// small coefficients once, then for each of its limbs (blockIdx.z, z + gridDim.z, ...) transforms them, adds the
+// intermediate's l values (for a fixed slot the 32 parties of a half-wave are 256 contiguous bytes) and the offset
+// correction, and stores its l slots -- 8 l bytes, the 16 parties of a row block side by side: whole 1-KiB runs of
+// the tiled public-key matrix.  No LDS tiles, no barriers after the sampling.  Only tiled_out + tiled_swap.
+template <int ELL>
+__global__ __launch_bounds__(256) void gemm_finish_keygen_kernel(GemmSection sec, DevTables t, u32 L, u32 nv, u32 nv_pad, u32 rows_pad,
+                                                                  const int* __restrict__ SY, size_t sy_b16, GemmErrSource es) {
+  constexpr int VPB = 8;                                         // columns per block (x 32 parties)
+  __shared__ i64 coef[256][ELL + 1];
+  const u32 tid = threadIdx.x, row = blockIdx.x * 32 + (tid & 31), v = blockIdx.y * VPB + (tid >> 5);
+  const bool valid = row < sec.nrows && v < nv;
+  i64 c[ELL];
+  {
+    i64* o = coef[tid];
+    if (!valid) {
+#pragma unroll
+      for (int sl = 0; sl < ELL; ++sl) o[sl] = 0;
+    } else if (es.explicit_coeffs) {
+      const i64* ec = es.explicit_coeffs + ((size_t)row * nv + v) * ELL;
+#pragma unroll
+      for (int sl = 0; sl < ELL; sl += 2) *reinterpret_cast<v2u64*>(o + sl) = *reinterpret_cast<const v2u64*>(ec + sl);
+    } else {
+      ChaChaRng g;
+      g.init(es.key, es.domain, es.index0 + row * es.index_row + v);
+      auto emit = [o](u32 sl, i64 val) { o[sl] = val; };       // (dynamic index: through LDS, then into registers)
+      sample_uniform_poly(g, ELL, es.bound, emit);
+    }
+#pragma unroll
+    for (int sl = 0; sl < ELL; ++sl) c[sl] = o[sl];             // own row of the array: no barrier needed
+  }
+  if (!valid) return;
+  const u32 vc = v < nv ? v : nv - 1;
+  const u64* tbase = sec.tmp + (vc >> 4) * sec.tmp_bstride + (size_t)(nv_pad == 16 ? (vc & 15) : vc) * rows_pad + row;
+  const size_t sstride = (size_t)nv_pad * rows_pad;             // words between consecutive slots of the intermediate
+  const u64* cbase = reinterpret_cast<const u64*>(SY + (size_t)(vc >> 4) * sy_b16 + ((size_t)((vc & 15) >> 2) * L * ELL) * 32) + (vc & 3);
+  constexpr u32 R = 128 / ELL;
+  const u32 prow = sec.tiled_row0 + row;                         // party; the column of B is the GEMM vector
+  u64 in[ELL];
+  auto load_tmp = [&](u32 limb) {
+#pragma unroll
+    for (int sl = 0; sl < ELL; ++sl) in[sl] = __builtin_nontemporal_load(tbase + ((size_t)limb * ELL + sl) * sstride);
+  };
+  u32 limb = blockIdx.z;
+  if (limb < L) load_tmp(limb);
+  for (; limb < L; limb += gridDim.z) {
+    const Mod m = t.mods[limb];
+    u64 a[ELL], x[ELL];
+#pragma unroll
+    for (int sl = 0; sl < ELL; ++sl) { a[sl] = signed_residue(c[sl], m); x[sl] = in[sl]; }
+    if (limb + gridDim.z < L) load_tmp(limb + gridDim.z);        // the next limb's intermediate arrives under this transform
+    ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, m);
+    u64* o = sec.tiled_out + (((size_t)(prow / R) * L + limb) * nv + v) * 128 + (prow % R) * ELL;
+#pragma unroll
+    for (int sl = 0; sl < ELL; sl += 2) {
+      const u64 c0 = cbase[((size_t)limb * ELL + sl) * 16], c1 = cbase[((size_t)limb * ELL + sl + 1) * 16];   // SY records are 32 ints
+      *reinterpret_cast<v2u64*>(o + sl) = (v2u64){addmod(addmod(x[sl], a[sl], m.q), c0, m.q), addmod(addmod(x[sl + 1], a[sl + 1], m.q), c1, m.q)};
+    }
+  }
+}
+
 #if PVW_TUNING
 // ------------------------------------------------------------------------------------
 // read-bandwidth probe (self-test / measurement aid): the loads of mac_rows -- 1-KiB tiles, 16 bytes per lane,
@@ -3145,6 +3259,23 @@ hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u
   return hipGetLastError();
 }
 
+hipError_t launch_shat_mftile(const i64* coeffs, u64* XM, u32 rows, u32 k, u32 L, u32 ell, const DevTables& t, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  if (ell > 32) return hipErrorInvalidValue;                 // callers keep the prologue + launch_mftile pair for l = 64
+  const u32 jbg = 2;
+  const u32 JB = (k + 3) / 4, JG = (JB + jbg - 1) / jbg;
+  const u32 RT = ((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * (PVW_GEMM_ROWS_PER_WG / 32);
+  u32 ls = 1;                                                 // limb interleave: enough blocks for several rounds on the chip
+  while (ls < L && (size_t)JG * RT * ls < 4096) ls *= 2;
+  if (ls > L) ls = L;
+  switch (ell) {
+    case 8: shat_mftile_kernel<8><<<dim3(JG, RT, ls), dim3(256), 0, s>>>(coeffs, XM, rows, k, L, t); break;
+    case 16: shat_mftile_kernel<16><<<dim3(JG, RT, ls), dim3(256), 0, s>>>(coeffs, XM, rows, k, L, t); break;
+    default: shat_mftile_kernel<32><<<dim3(JG, RT, ls), dim3(256), 0, s>>>(coeffs, XM, rows, k, L, t); break;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
                              const DevTables& t, hipStream_t s, size_t lstride, size_t jstride) {
   if (nv == 0) return hipSuccess;
@@ -3171,7 +3302,7 @@ hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, i
 
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
-                              hipStream_t s) {
+                              hipStream_t s, const GemmErrSource* es) {
   GemmSection sa = a, sb = b;
   sa.rt_groups = (sa.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
   sb.rt_groups = (sb.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
@@ -3221,6 +3352,21 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
     default: return hipErrorInvalidValue;
   }
 #undef PVW_GEMM_LAUNCH
+  }
+  if (es) {
+    // key generation, errors made in the finish pass: section a only, tiled_out + tiled_swap, l <= 32
+    if (!sa.nrows || sb.nrows || !sa.tiled_out || !sa.tiled_swap || ell > 32) return hipErrorInvalidValue;
+    u32 lz = 1;                                              // limb interleave: enough blocks for several rounds on the chip
+    while (lz < L && (size_t)((sa.nrows + 31) / 32) * ((nv + 7) / 8) * lz < 4096) lz *= 2;
+    if (lz > L) lz = L;
+    const dim3 grid((sa.nrows + 31) / 32, (nv + 7) / 8, lz);
+    const u32 rows_pad = sa.rt_groups * PVW_GEMM_ROWS_PER_WG;
+    switch (ell) {
+      case 8: gemm_finish_keygen_kernel<8><<<grid, dim3(256), 0, s>>>(sa, t, L, nv, nv_pad, rows_pad, SY, sy_b16, *es); break;
+      case 16: gemm_finish_keygen_kernel<16><<<grid, dim3(256), 0, s>>>(sa, t, L, nv, nv_pad, rows_pad, SY, sy_b16, *es); break;
+      default: gemm_finish_keygen_kernel<32><<<grid, dim3(256), 0, s>>>(sa, t, L, nv, nv_pad, rows_pad, SY, sy_b16, *es); break;
+    }
+    return hipGetLastError();
   }
   if (sa.nrows) {
     PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sa.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
