@@ -1344,6 +1344,8 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
     PVW_TRY(ensure_xm(c, s));
   }
   const size_t group = use_gemm ? (size_t)16 * gemm_vb() : 4;
+  // matrix-core passes: the c2 finish pass draws e2 and encodes the scalars itself (tuning build: PVW_FUSED_E2=0 the prologue does)
+  const bool fused_e2 = use_gemm && l <= 32 && PVW_ENV_INT("PVW_FUSED_E2", 1) != 0;
   u64* vh = use_gemm ? w->vhat16 : w->rhat;
   for (size_t d0 = 0; d0 < D; d0 += group) {
     const u32 nv = (u32)((D - d0) < group ? (D - d0) : group);
@@ -1364,7 +1366,7 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
       pb.job[1].rep_out = (size_t)rA * P;                      // c1 planes
       pb.job[2].rep_out = (size_t)rB * P;                      // c2 planes
       pb.job[2].rep_scalars = c->n;
-      pb.njobs = 3;
+      pb.njobs = fused_e2 ? 2 : 3;                              // fused: e2 + m g-hat are made by the c2 finish pass
       pb.reps = cnt;
       ProfScope ps(c, "prologue", s);
       PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
@@ -1378,7 +1380,21 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
       }
       ProfScope ps(c, "gemm_digits", s);
       GemmSection a{c->xmA, c1g, c1g, w->gtmpA, rA, 0, 0}, b{c->xmB, c2g, c2g, w->gtmpB, rB, 0, 0};
-      PVW_HIP(launch_gemm_digits(a, b, w->yd, w->sy, c->dt, k, L, l, nv, (size_t)rA * P, (size_t)rB * P, s));
+      std::vector<GemmErrSource> es;
+      if (fused_e2) {
+        // e2_d[i] (encryption.rs:195-196): dealer d's key, stream DOM_E2 / party index, uniform in [-b2, b2]; + m_{d,i} g-hat
+        for (u32 v0 = 0; v0 < nv; v0 += PVW_MAX_PROLOGUE_KEYS) {
+          GemmErrSource e{};
+          e.span = (nv - v0) < PVW_MAX_PROLOGUE_KEYS ? (nv - v0) : PVW_MAX_PROLOGUE_KEYS;
+          for (u32 x = 0; x < e.span; ++x) e.key[x] = make_key(seeds + (d0 + v0 + x) * 32);
+          e.key_v = 1;
+          e.domain = DOM_E2; e.index0 = c->party_lo; e.index_row = 1; e.index_v = 0; e.bound = c->b2;
+          e.scalars = d_scalars + d0 * c->n + c->party_lo; e.scalar_v = c->n;
+          es.push_back(e);
+        }
+        b.addend = nullptr;
+      }
+      PVW_HIP(launch_gemm_digits(a, b, w->yd, w->sy, c->dt, k, L, l, nv, (size_t)rA * P, (size_t)rB * P, s, nullptr, fused_e2 ? es.data() : nullptr));
     } else {
       ProfScope ps(c, "mac_rows_multi", s);
       MacSection a{c->dA, c1g, c1g, rA, 0}, b{c->dB, c2g, c2g, rB, 0};
@@ -1935,9 +1951,9 @@ static int32_t keygen_gemm_swapped(pvw_ctx* c, Workspace* w, u32 a, u32 b, u32 l
     if (direct) {
       PVW_HIP(launch_shat_mftile(d_small, d_xm, cnt, k, L, l, c->dt, s));
       GemmErrSource es{};
-      if (ek) es.explicit_coeffs = d_small + (size_t)chunk * k * l;
-      else es.key = make_key(seed);
-      es.domain = DOM_EKEY; es.index0 = p0 * k; es.index_row = k; es.bound = c->b1;
+      if (ek) { es.explicit_coeffs = d_small + (size_t)chunk * k * l; es.coef_row = k; es.coef_v = 1; }
+      else es.key[0] = make_key(seed);
+      es.domain = DOM_EKEY; es.index0 = p0 * k; es.index_row = k; es.index_v = 1; es.bound = c->b1;
       ga.addend = nullptr;
       ga.out = nullptr;
       // all k columns in one launch (crs.rs:152-168)

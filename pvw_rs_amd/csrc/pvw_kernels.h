@@ -183,17 +183,24 @@ hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, i
                              const DevTables& t, hipStream_t s, size_t lstride = 0, size_t jstride = 0);
 // nv may exceed 16: batches of 16 vectors then run as extra workgroups of ONE launch (adjacent in dispatch
 // order, so they share the streamed matrix tiles through L2); tmp must hold ceil(nv/16) batches.
-// es != NULL (key generation; section a with tiled_out + tiled_swap, no section b, l <= 32): the finish pass adds
-// the key errors it draws or reads itself (GemmErrSource) instead of an addend from memory.
+// es_a / es_b != NULL (l <= 32): that section's finish pass adds an error term it draws or reads itself, plus the
+// encoded scalar, instead of an addend from memory (gemm_finish_err_kernel).  (row, v) = (GEMM row, vector).
+// The pointer is to an ARRAY: element i describes the next `span` vectors (its keys travel as kernel arguments,
+// 64 at most); span == 0 covers all that are left.
 struct GemmErrSource {
-  const i64* explicit_coeffs;   // [row][nv][l] small coefficients, or NULL: drawn uniformly in [-bound, bound]
-  ChaChaKey key;
-  u32 domain, index0, index_row;   // ChaCha stream of (row, v): index0 + row * index_row + v
-  u64 bound;
+  u32 span;
+  const i64* explicit_coeffs;       // small coefficients of (row, v) at (row * coef_row + v * coef_v) * l, or NULL: drawn
+  size_t coef_row, coef_v;
+  ChaChaKey key[PVW_MAX_PROLOGUE_KEYS];   // key of vector v: key[(v - first vector of this element) * key_v]
+  u32 key_v;
+  u32 domain, index0, index_row, index_v;   // ChaCha stream of (row, v): index0 + row * index_row + v * index_v
+  u64 bound;                        // uniform in [-bound, bound]
+  const u64* scalars;               // NULL, or m of (row, v) at scalars[v * scalar_v + row]: + m g-hat (encode_scalar)
+  size_t scalar_v;
 };
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
-                              hipStream_t s, const GemmErrSource* es = nullptr);
+                              hipStream_t s, const GemmErrSource* es_a = nullptr, const GemmErrSource* es_b = nullptr);
 // read-only probe: every wave streams `tiles` consecutive 1-KiB tiles (16 in flight), grid as mac_rows
 #if PVW_TUNING
 // time stamps (100 MHz ticks, [2b] start / [2b+1] end) and HW_ID words of the workgroups of the last stamped mac_rows launch

@@ -2716,67 +2716,100 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
     }
 }
 
-// gemm_finish for key generation with the key errors made on the spot: b_p[col] = (s_p A)[col] + e_p[col]
-// (public_key.rs:128-147), e_p[col] either drawn here (the ChaCha stream and rejection sampler of the prologue:
-// uniform in [-bound, bound], stream index0 + p * index_row + col) or read as explicit coefficients [p][col][l]; no
-// transformed error rows in memory, no prologue launch.  One THREAD = (party, column): it makes the polynomial's
-// small coefficients once, then for each of its limbs (blockIdx.z, z + gridDim.z, ...) transforms them, adds the
-// intermediate's l values (for a fixed slot the 32 parties of a half-wave are 256 contiguous bytes) and the offset
-// correction, and stores its l slots -- 8 l bytes, the 16 parties of a row block side by side: whole 1-KiB runs of
-// the tiled public-key matrix.  No LDS tiles, no barriers after the sampling.  Only tiled_out + tiled_swap.
+// gemm_finish with the error term made on the spot instead of read as an addend:
+//   key generation   b_p[col] = (s_p A)[col] + e_p[col]                    (public_key.rs:128-147), into the tiled B-hat;
+//   multi-dealer c2  c2_d[i]  = (B r_d)[i] + e2_d[i] + m_{d,i} g-hat        (encryption.rs:177-200), into the API planes.
+// The error polynomial of (GEMM row, vector) is drawn here -- the ChaCha stream and rejection sampler of the prologue,
+// uniform in [-bound, bound], key and stream index from GemmErrSource -- or read as explicit small coefficients; no
+// transformed error rows in memory, no prologue work for them.  One THREAD = (row, vector): it makes the small
+// coefficients once, then for each of its limbs (a contiguous range per blockIdx.z) transforms them, adds the
+// intermediate's l values (for a fixed slot the 32 rows of a half-wave are 256 contiguous bytes), the offset
+// correction and the encoded scalar.  The finished l slots (8 l bytes per thread) go through the wave's own LDS rows
+// so that l / 2 neighbouring lanes write ONE row's 8 l contiguous bytes per store instead of 16 bytes each of l / 2
+// rows (API layout: rows are 8 L l bytes apart).  No block-wide barriers.
 template <int ELL>
-__global__ __launch_bounds__(256) void gemm_finish_keygen_kernel(GemmSection sec, DevTables t, u32 L, u32 nv, u32 nv_pad, u32 rows_pad,
-                                                                  const int* __restrict__ SY, size_t sy_b16, GemmErrSource es) {
-  constexpr int VPB = 8;                                         // columns per block (x 32 parties)
-  __shared__ i64 coef[256][ELL + 1];
-  const u32 tid = threadIdx.x, row = blockIdx.x * 32 + (tid & 31), v = blockIdx.y * VPB + (tid >> 5);
-  const bool valid = row < sec.nrows && v < nv;
+__global__ __launch_bounds__(256) void gemm_finish_err_kernel(GemmSection sec, DevTables t, u32 L, u32 nv, u32 nv_pad, u32 rows_pad,
+                                                               size_t ostride, const int* __restrict__ SY, size_t sy_b16, GemmErrSource es,
+                                                               u32 v_lo, u32 v_hi) {
+  constexpr int VPB = 8;                                         // vectors per block (x 32 rows)
+  constexpr int G = ELL / 2;                                     // lanes that share out one another's 8 l bytes (16 each)
+  constexpr int CST = ELL + 2;                                   // LDS words per thread (16-byte aligned, bank spread)
+  __shared__ i64 coef[256 * CST];
+  const u32 tid = threadIdx.x, lane = tid & 63;
+  const u32 row_raw = blockIdx.x * 32 + (tid & 31), v_raw = v_lo + blockIdx.y * VPB + (tid >> 5);   // this launch: vectors [v_lo, v_hi)
+  // every lane stays: a lane past the end still carries 16-byte pieces of its neighbours' rows to memory
+  const bool v_ok = v_raw < v_hi;
+  const u32 row = row_raw < sec.nrows ? row_raw : sec.nrows - 1, v = v_ok ? v_raw : v_hi - 1;
   i64 c[ELL];
   {
-    i64* o = coef[tid];
-    if (!valid) {
-#pragma unroll
-      for (int sl = 0; sl < ELL; ++sl) o[sl] = 0;
-    } else if (es.explicit_coeffs) {
-      const i64* ec = es.explicit_coeffs + ((size_t)row * nv + v) * ELL;
+    i64* o = coef + tid * CST;
+    if (es.explicit_coeffs) {
+      const i64* ec = es.explicit_coeffs + ((size_t)row * es.coef_row + (size_t)v * es.coef_v) * ELL;
 #pragma unroll
       for (int sl = 0; sl < ELL; sl += 2) *reinterpret_cast<v2u64*>(o + sl) = *reinterpret_cast<const v2u64*>(ec + sl);
     } else {
       ChaChaRng g;
-      g.init(es.key, es.domain, es.index0 + row * es.index_row + v);
+      g.init(es.key[(v - v_lo) * es.key_v], es.domain, es.index0 + row * es.index_row + v * es.index_v);
       auto emit = [o](u32 sl, i64 val) { o[sl] = val; };       // (dynamic index: through LDS, then into registers)
       sample_uniform_poly(g, ELL, es.bound, emit);
     }
 #pragma unroll
     for (int sl = 0; sl < ELL; ++sl) c[sl] = o[sl];             // own row of the array: no barrier needed
   }
-  if (!valid) return;
-  const u32 vc = v < nv ? v : nv - 1;
-  const u64* tbase = sec.tmp + (vc >> 4) * sec.tmp_bstride + (size_t)(nv_pad == 16 ? (vc & 15) : vc) * rows_pad + row;
+  const i64 scalar = es.scalars ? (i64)es.scalars[(size_t)v * es.scalar_v + row] : 0;   // `as i64` wrap, encryption.rs:195
+  const u64* tbase = sec.tmp + (v >> 4) * sec.tmp_bstride + (size_t)(nv_pad == 16 ? (v & 15) : v) * rows_pad + row;
   const size_t sstride = (size_t)nv_pad * rows_pad;             // words between consecutive slots of the intermediate
-  const u64* cbase = reinterpret_cast<const u64*>(SY + (size_t)(vc >> 4) * sy_b16 + ((size_t)((vc & 15) >> 2) * L * ELL) * 32) + (vc & 3);
+  const u64* cbase = reinterpret_cast<const u64*>(SY + (size_t)(v >> 4) * sy_b16 + ((size_t)((v & 15) >> 2) * L * ELL) * 32) + (v & 3);
   constexpr u32 R = 128 / ELL;
-  const u32 prow = sec.tiled_row0 + row;                         // party; the column of B is the GEMM vector
+  const size_t rstride = sec.row_stride ? sec.row_stride : (size_t)L * ELL;
   u64 in[ELL];
   auto load_tmp = [&](u32 limb) {
 #pragma unroll
     for (int sl = 0; sl < ELL; ++sl) in[sl] = __builtin_nontemporal_load(tbase + ((size_t)limb * ELL + sl) * sstride);
   };
-  u32 limb = blockIdx.z;
-  if (limb < L) load_tmp(limb);
-  for (; limb < L; limb += gridDim.z) {
+  // this block's limbs: a contiguous range (a thread's stores then fill neighbouring lines one after the other)
+  const u32 per = (L + gridDim.z - 1) / gridDim.z, limb_end = (blockIdx.z + 1) * per < L ? (blockIdx.z + 1) * per : L;
+  u32 limb = blockIdx.z * per;
+  if (limb < limb_end) load_tmp(limb);
+  // the wave's staging rows (the coefficient rows, free once c[] is loaded): lane x's finished l slots at stg + x * CST
+  u64* stg = reinterpret_cast<u64*>(coef) + (size_t)(tid - lane) * CST;
+  const u32 gi = lane & (G - 1), gb = lane & ~(u32)(G - 1);      // piece this lane carries; first lane of its group
+  for (; limb < limb_end; ++limb) {
     const Mod m = t.mods[limb];
     u64 a[ELL], x[ELL];
 #pragma unroll
     for (int sl = 0; sl < ELL; ++sl) { a[sl] = signed_residue(c[sl], m); x[sl] = in[sl]; }
-    if (limb + gridDim.z < L) load_tmp(limb + gridDim.z);        // the next limb's intermediate arrives under this transform
+    if (limb + 1 < limb_end) load_tmp(limb + 1);                 // the next limb's intermediate arrives under this transform
     ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, m);
-    u64* o = sec.tiled_out + (((size_t)(prow / R) * L + limb) * nv + v) * 128 + (prow % R) * ELL;
+    if (es.scalars) {                                            // encode_scalar (parameters.rs:346-367): + m g-hat
+      const u64 mr = signed_residue(scalar, m);
+      const u64* g = t.ghat + (size_t)limb * ELL;
+      const u64* gp = t.ghatp + (size_t)limb * ELL;
+#pragma unroll
+      for (int sl = 0; sl < ELL; ++sl) a[sl] = addmod(a[sl], mulmod_shoup(mr, g[sl], gp[sl], m.q), m.q);
+    }
 #pragma unroll
     for (int sl = 0; sl < ELL; sl += 2) {
       const u64 c0 = cbase[((size_t)limb * ELL + sl) * 16], c1 = cbase[((size_t)limb * ELL + sl + 1) * 16];   // SY records are 32 ints
-      *reinterpret_cast<v2u64*>(o + sl) = (v2u64){addmod(addmod(x[sl], a[sl], m.q), c0, m.q), addmod(addmod(x[sl + 1], a[sl + 1], m.q), c1, m.q)};
+      *reinterpret_cast<v2u64*>(stg + lane * CST + sl) =
+          (v2u64){addmod(addmod(x[sl], a[sl], m.q), c0, m.q), addmod(addmod(x[sl + 1], a[sl + 1], m.q), c1, m.q)};
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // store j: the G lanes of a group write the 8 l contiguous bytes of the group's j-th row, 16 bytes each
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const v2u64 pv = *reinterpret_cast<const v2u64*>(stg + (gb + j) * CST + 2 * gi);
+      const u32 rj = row_raw - gi + j;                           // the row lane gb + j works on (before clamping)
+      if (rj < sec.nrows && v_ok) {
+        const u32 prow = sec.tiled_row0 + rj;                    // tiled form: the party; the column of B is the GEMM vector
+        u64* o = sec.tiled_out ? sec.tiled_out + (((size_t)(prow / R) * L + limb) * nv + v) * 128 + (prow % R) * ELL
+                               : sec.out + (size_t)v * ostride + (size_t)rj * rstride + (size_t)limb * ELL;
+        *reinterpret_cast<v2u64*>(o + 2 * gi) = pv;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                             // the staging rows are rewritten for the next limb
   }
 }
 
@@ -3302,7 +3335,7 @@ hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, i
 
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
-                              hipStream_t s, const GemmErrSource* es) {
+                              hipStream_t s, const GemmErrSource* es_a, const GemmErrSource* es_b) {
   GemmSection sa = a, sb = b;
   sa.rt_groups = (sa.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
   sb.rt_groups = (sb.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
@@ -3353,30 +3386,36 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   }
 #undef PVW_GEMM_LAUNCH
   }
-  if (es) {
-    // key generation, errors made in the finish pass: section a only, tiled_out + tiled_swap, l <= 32
-    if (!sa.nrows || sb.nrows || !sa.tiled_out || !sa.tiled_swap || ell > 32) return hipErrorInvalidValue;
-    u32 lz = 1;                                              // limb interleave: enough blocks for several rounds on the chip
-    while (lz < L && (size_t)((sa.nrows + 31) / 32) * ((nv + 7) / 8) * lz < 4096) lz *= 2;
-    if (lz > L) lz = L;
-    const dim3 grid((sa.nrows + 31) / 32, (nv + 7) / 8, lz);
-    const u32 rows_pad = sa.rt_groups * PVW_GEMM_ROWS_PER_WG;
-    switch (ell) {
-      case 8: gemm_finish_keygen_kernel<8><<<grid, dim3(256), 0, s>>>(sa, t, L, nv, nv_pad, rows_pad, SY, sy_b16, *es); break;
-      case 16: gemm_finish_keygen_kernel<16><<<grid, dim3(256), 0, s>>>(sa, t, L, nv, nv_pad, rows_pad, SY, sy_b16, *es); break;
-      default: gemm_finish_keygen_kernel<32><<<grid, dim3(256), 0, s>>>(sa, t, L, nv, nv_pad, rows_pad, SY, sy_b16, *es); break;
+  // a section with an error source: gemm_finish_err_kernel (l <= 32; the tiled form only with tiled_swap)
+  auto finish = [&](const GemmSection& sec, size_t ostride, const GemmErrSource* es) -> hipError_t {
+    if (!sec.nrows) return hipSuccess;
+    const u32 rows_pad = sec.rt_groups * PVW_GEMM_ROWS_PER_WG;
+    if (es) {
+      if (ell > 32 || (sec.tiled_out && !sec.tiled_swap) || (!sec.tiled_out && !sec.out)) return hipErrorInvalidValue;
+      // one launch per GemmErrSource of the array: es[i] covers the next es[i].span vectors (0: all that are left)
+      for (u32 v_lo = 0; v_lo < nv; ++es) {
+        const u32 span = es->span && es->span < nv - v_lo ? es->span : nv - v_lo, v_hi = v_lo + span;
+        const u32 gx = (sec.nrows + 31) / 32, gy = (span + 7) / 8;
+        u32 lz = 1;                                          // limb interleave: enough blocks for several rounds on the chip
+        while (lz < L && (size_t)gx * gy * lz < 4096) lz *= 2;
+        if (lz > L) lz = L;
+        const dim3 grid(gx, gy, lz);
+        switch (ell) {
+          case 8: gemm_finish_err_kernel<8><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+          case 16: gemm_finish_err_kernel<16><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+          default: gemm_finish_err_kernel<32><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+        }
+        v_lo = v_hi;
+      }
+      return hipGetLastError();
     }
+    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sec.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
+                              sec, t.mods, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16));
     return hipGetLastError();
-  }
-  if (sa.nrows) {
-    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sa.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
-                              sa, t.mods, L, nv, nv_pad, sa.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_a, SY, sy_b16));
-  }
-  if (sb.nrows) {
-    PVW_DISPATCH_ELL(ell, gemm_finish_kernel<E><<<dim3((sb.nrows + 31) / 32, (nv + (E >= 64 ? 2 : 4) - 1) / (E >= 64 ? 2 : 4), L), dim3(256), 0, s>>>(
-                              sb, t.mods, L, nv, nv_pad, sb.rt_groups * PVW_GEMM_ROWS_PER_WG, ostride_b, SY, sy_b16));
-  }
-  return hipGetLastError();
+  };
+  hipError_t fe = finish(sa, ostride_a, es_a);
+  if (fe != hipSuccess) return fe;
+  return finish(sb, ostride_b, es_b);
 }
 
 #if PVW_TUNING
