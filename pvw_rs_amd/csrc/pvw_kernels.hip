@@ -2471,7 +2471,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 // The epilogue is gemm_digits_kernel's (gemm_recombine, intermediate [limb][slot][v][row], gemm_finish).
 // Needs k % 16 == 0 (whole stages); the launcher falls back to gemm_digits_kernel otherwise and for <= 16 vectors.
 // ------------------------------------------------------------------------------------
-template <int ELL, bool FASTQ, int WRN>
+template <int ELL, bool FASTQ, int WRN, bool PP = false>
 __global__ __launch_bounds__(128 * WRN, 2) void gemm_digits_wide_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
                                                                          const Mod* __restrict__ mods, u32 k, u32 L, u32 nv_total,
                                                                          u32 nv_pad, u32 vbn, size_t yd_b16) {
@@ -2585,6 +2585,58 @@ __global__ __launch_bounds__(128 * WRN, 2) void gemm_digits_wide_kernel(GemmSect
 #pragma unroll
   for (int i = 0; i < NB - 1; ++i)
     if ((u32)i < NST) issue(i);
+  if constexpr (PP) {
+    // Ping-pong (8 waves): the waves of a SIMD, w and w + 4, run half a stage apart -- while one issues its 16 MFMAs
+    // the other reads its 12 fragments and sits out the waits, so the matrix pipe is not left idle
+    // by instructions that cost issue time.  Phases are separated by barriers every wave executes; group B (waves
+    // 4-7) starts one barrier late and group A takes one extra at the end.
+    //   A:  L0 | M0 | L1 | M1 | ...        L_s: fragments of stage s -> registers, lgkmcnt(0)
+    //   B:     | L0 | M0 | L1 | ...        M_s: 16 MFMAs, the wave's DMAs of stage s + 3 in their gaps
+    // Stage s is read first by A's L_s; every wave waits for its own DMAs of stage s in the phase before that
+    // (A: end of M_{s-1}, B: end of L_{s-1}; two younger stages stay in flight).  The buffer of stage s - 1 is
+    // refilled (DMAs of stage s + 3) only in M_s, after the barrier that follows B's L_{s-1}, whose lgkmcnt(0)
+    // retired the last reads of it.
+    static_assert(!PP || (WRN == 4 && NB == 4), "ping-pong: the 8-wave form");
+    const bool grp_b = wave >= 4;
+    wait_stages(NST - 1 < 2u ? NST - 1 : 2u);                // stage 0 has landed (mine; the barrier: everyone's)
+    __builtin_amdgcn_s_barrier();
+    if (grp_b) __builtin_amdgcn_s_barrier();
+    for (u32 st = 0; st < NST; ++st) {
+      // stages that may stay in flight while a wave waits for its DMAs of stage st + 1: B waits at the end of L_st
+      // (newest issued: st + 2), A at the end of M_st (newest: st + 3)
+      const u32 last = NST - 1;
+      const u32 ahead_b = (st + 2 < last ? st + 2 : last) > st + 1 ? (st + 2 < last ? st + 2 : last) - (st + 1) : 0;
+      const u32 ahead_a = (st + 3 < last ? st + 3 : last) > st + 1 ? (st + 3 < last ? st + 3 : last) - (st + 1) : 0;
+      const bool dma = st + 3 < NST;
+      read(f0, st, 0);
+      read(f1, st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp_b && st + 1 < NST) wait_stages(ahead_b);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (i >> 2) & 1, g = i & 3;
+        const v4i32(&f)[6] = i < 8 ? f0 : f1;
+        if (PVW_ABL(32)) acc[r][g][0] += f[2 + g][0] ^ f[r][0];
+        else acc[r][g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f[2 + g], f[r], acc[r][g], 0, 0, 0);
+        // this wave's four DMAs of stage st + 3 ride in the gaps of its own MFMAs (a DMA costs ~60 cycles of issue
+        // against the 32 of the MFMA in front of it; in the L phase it would lengthen the phase the partner waits on)
+        if ((i & 3) == 3 && dma) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_one(st + 3, i >> 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!grp_b && st + 1 < NST) wait_stages(ahead_a);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!grp_b) __builtin_amdgcn_s_barrier();
+  } else {
   if constexpr (CROSS) {
     wait_stages(NST - 1 < (u32)(NB - 2) ? NST - 1 : (u32)(NB - 2));    // stage 0 has landed (mine; the barrier: everyone's)
     __builtin_amdgcn_s_barrier();
@@ -2602,6 +2654,7 @@ __global__ __launch_bounds__(128 * WRN, 2) void gemm_digits_wide_kernel(GemmSect
     if constexpr (!CROSS) read(f0, st, 0);
     mac_and_read(f0, f1, st, 1, true, st + NB - 1, dma, 0);
     mac_and_read(f1, f0, st + 1 < NST ? st + 1 : st, 0, CROSS, st + NB - 1, dma, GPS / 2);   // past the end: a harmless re-read
+  }
   }
   if (PVW_ABL(64)) {                                         // timing experiment: no epilogue
     int keep = 0;
@@ -3353,24 +3406,34 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
     if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, true><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16)); } \
     else { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, false><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, dbg, vbn, yd_b16, sy_b16)); } \
   } while (0)
+#if PVW_TUNING
+  // timing experiment (results wrong): all-zero operand bytes, to separate the schedule from the data-dependent power draw
+  if (PVW_ENV_INT("PVW_GEMM_ZERO_OPERANDS", 0)) {
+    if (sa.nrows) (void)hipMemsetAsync(const_cast<u64*>(sa.XM), 0, xm_words(sa.nrows, k, L, ell) * 8, s);
+    if (sb.nrows) (void)hipMemsetAsync(const_cast<u64*>(sb.XM), 0, xm_words(sb.nrows, k, L, ell) * 8, s);
+    (void)hipMemsetAsync(const_cast<signed char*>(YD), 0, yd_b16 * vbn, s);
+  }
+#endif
   // more than 16 vectors and whole stages of 16 terms: the wide form (256 rows x 32 vectors per workgroup, both
   // operands through LDS).  PVW_GEMM_WIDE=0 in the tuning build selects gemm_digits_kernel everywhere.
   const bool wide = vbn >= 2 && k % 16 == 0 && k >= 16 && PVW_ENV_INT("PVW_GEMM_WIDE", 1) != 0;
   if (wide) {
-    // 4 waves (128 rows x 32 vectors, two workgroups per CU: one's epilogue under the other's MFMAs) or 8 waves (256 x 32)
-    [[maybe_unused]] const int wform = (int)PVW_ENV_INT("PVW_GEMM_WIDE", 2);
-#define PVW_GEMM_WIDE_LAUNCH(WRN)                                                                                          \
+    // shipped: 8 waves in ping-pong (256 rows x 32 vectors).  Tuning build, PVW_GEMM_WIDE: 1 = 8 waves in step, 2 = 4 waves
+    // (128 x 32, two workgroups per CU: one's epilogue under the other's MFMAs), 3 = the shipped form
+    [[maybe_unused]] const int wform = (int)PVW_ENV_INT("PVW_GEMM_WIDE", 3);
+#define PVW_GEMM_WIDE_LAUNCH(WRN, PP)                                                                                      \
   do {                                                                                                                    \
     const u32 ga = (sa.rt_groups * 4 + 2 * WRN - 1) / (2 * WRN), gb2 = (sb.rt_groups * 4 + 2 * WRN - 1) / (2 * WRN);       \
     const u32 wblocks = (ga + gb2) * L * ell * ((vbn + 1) / 2);                                                           \
-    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, true, WRN><<<dim3(wblocks), dim3(128 * WRN), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); } \
-    else { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, false, WRN><<<dim3(wblocks), dim3(128 * WRN), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); } \
+    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, true, WRN, PP><<<dim3(wblocks), dim3(128 * WRN), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); } \
+    else { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, false, WRN, PP><<<dim3(wblocks), dim3(128 * WRN), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); } \
   } while (0)
 #if PVW_TUNING
-    if (wform == 1) PVW_GEMM_WIDE_LAUNCH(4);
+    if (wform == 1) PVW_GEMM_WIDE_LAUNCH(4, false);
+    else if (wform == 2) PVW_GEMM_WIDE_LAUNCH(2, false);
     else
 #endif
-      PVW_GEMM_WIDE_LAUNCH(2);
+      PVW_GEMM_WIDE_LAUNCH(4, true);
 #undef PVW_GEMM_WIDE_LAUNCH
   } else {
   // fully unrolled chunk loops for the BASELINE geometries (k = 256: 8 chunks of 8 j-blocks, k = 512: 16), full vector groups

@@ -72,6 +72,14 @@ def test_device_decode_forms_match_model(l, moduli, monkeypatch):
     T.device_decode_case(l, moduli, lambda v: monkeypatch.setenv("PVW_DECODE_VARIANT", str(v)), (0, 3, 4, 2, 1))
 
 
+@pytest.mark.parametrize("D", [5, 70])
+def test_multi_dealer_encrypt_with_e2_from_the_prologue(D, monkeypatch):
+    # PVW_FUSED_E2=0: e2 + m g-hat come from the prologue as an addend of the c2 finish pass (the round-1 form) instead
+    # of being drawn inside it -- same ciphertexts (encryption.rs:195-196)
+    monkeypatch.setenv("PVW_FUSED_E2", "0")
+    T.multi_dealer_case(D)
+
+
 @pytest.mark.parametrize("n,k,l,L", [(150, 256, 8, 2), (70, 9, 8, 3)])
 def test_batched_keygen_transposed_crs_form(n, k, l, L, monkeypatch):
     # PVW_KEYGEN_SWAP=0: the transposed CRS is the streamed operand and super-groups of secret keys are digitised
@@ -116,3 +124,12 @@ def test_prologue_debug_switch_exists_only_in_the_tuning_build(monkeypatch):
     assert all(np.array_equal(a, b) for a, b in zip(got, want)), "the shipped library reacted to a debug variable"
     got_t = _encrypt_once("tuning")
     assert not np.array_equal(got_t[1], want[1]), "the tuning build should have skipped sampling"
+
+
+@pytest.mark.parametrize("form", [1, 2])
+def test_digit_gemm_wide_forms_agree(form, monkeypatch):
+    # PVW_GEMM_WIDE: 1 = 8 waves in step, 2 = 4 waves / two workgroups per CU (3, ping-pong, is what ships and what
+    # tests/test_gpu_parity.py runs): same ciphertexts from every form, k = 256 and k = 512
+    monkeypatch.setenv("PVW_GEMM_WIDE", str(form))
+    T.test_digit_gemm_multi_dealer_equals_separate_encrypts(100, 256, 8, 3, 40)
+    T.test_digit_gemm_multi_dealer_equals_separate_encrypts(40, 512, 16, 2, 17)
