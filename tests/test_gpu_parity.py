@@ -429,6 +429,8 @@ def multi_dealer_case(D):
     (40, 512, 16, 2, 17),     # k = 512: the 16-chunk unrolled form, one full batch + one dealer
     (6, 24, 64, 2, 9),        # l = 64
     (9, 8, 8, 3, 130),        # more dealers than one launch takes (128)
+    (20, 528, 8, 2, 40),      # k > 512 in the wide form: unbiased integer recombination
+    (37, 16, 8, 2, 33),       # the smallest k the wide form takes (two stages), ragged rows, three batches
 ])
 def test_digit_gemm_multi_dealer_equals_separate_encrypts(n, k, l, L, D):
     # >= 3 dealers take the matrix-core path (gemm_digits_kernel): i8 MFMA over byte-folded operands
@@ -674,7 +676,9 @@ def test_random_geometries_full_pipeline_against_c_oracle(case):
 @pytest.mark.parametrize("n,k,l,L", [(150, 256, 8, 2), (70, 9, 8, 3), (1100, 32, 16, 2),
                                             (3100, 8, 8, 2),      # four 1024-party chunks: both key buffers reused
                                             (40, 24, 8, 2),       # below 64 parties: transposed CRS as the streamed operand
-                                            (5, 12, 8, 2)])       # below 8: four per pass on the integer VALU
+                                            (5, 12, 8, 2),        # below 8: four per pass on the integer VALU
+                                            (70, 12, 32, 2),      # l = 32: 16 lanes share out a row in the fused finish pass
+                                            (66, 528, 8, 2)])     # k > 512: wide GEMM with the unbiased integer recombination
 def test_batched_keygen_super_groups_against_c_oracle(n, k, l, L):
     # pvw_keygen on the matrix cores (public_key.rs:111-147, crs.rs:138-171) against the C restatement, with seeded
     # and with explicit key errors.  From 64 parties up the parties are the GEMM rows and the CRS columns are
