@@ -1260,7 +1260,7 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
   const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
   PrologueBatch pb{};
   PVW_TRY(fill_encrypt_jobs(c, pb, 0, 0, rnd, d_scalars, w->rhat, d_c1, d_c2));
-  pb.njobs = 3;
+  pb.njobs = (u32)PVW_ENV_INT("PVW_PROLOGUE_JOBS", 3);     // tuning build, timing experiment (results wrong): 1 = r only
   {
     ProfScope ps(c, "prologue", s);
     PVW_HIP(launch_prologue(pb, c->dt, L, l, s));

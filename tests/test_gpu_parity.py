@@ -460,6 +460,47 @@ def test_digit_gemm_multi_dealer_equals_separate_encrypts(n, k, l, L, D):
         assert np.array_equal(many[d].c1, c1o) and np.array_equal(many[d].c2, c2o), f"dealer {d} vs oracle"
 
 
+@pytest.mark.parametrize("n,k,l,L,D", [(64, 256, 8, 2, 20), (40, 512, 8, 2, 17), (33, 512, 16, 2, 18)])
+def test_digit_gemm_extreme_matrix_bytes_against_c_oracle(n, k, l, L, D):
+    # The digit GEMM feeds the matrix elements to the i8 MFMA as raw bytes offset by -128 and recombines biased
+    # accumulators in f64 (exact while |half-sum| < 2^51, i.e. k <= 512): matrices made of the byte patterns that
+    # push the partial sums to their extremes -- all bytes 0x00 (-128 after the offset), q - 1 and 0x..ffff (+127),
+    # 0x80.. (0), alternating -- must still give the oracle's ciphertexts (crs.rs:188-201, encryption.rs:177-200)
+    moduli = M.bench_moduli(L)
+    p = build_params(n, k, l, moduli)
+    rng = np.random.default_rng(k + l)
+    q = np.array(moduli, dtype=np.uint64)[None, None, :, None]
+
+    def patterned(rows):
+        m = np.empty((rows, k, L, l), dtype=np.uint64)
+        pats = [0, 0xFFFFFFFFFFFFFFFF, 0x8080808080808080, 0x7F7F7F7F7F7F7F7F, 0x00FF00FF00FF00FF, 0xFF00FF00FF00FF00,
+                0x0000000000000001, 0x8000000000000000]
+        for i in range(rows):
+            if i % 3 == 2:
+                m[i] = rng.integers(0, 1 << 61, size=(k, L, l), dtype=np.uint64)
+            else:
+                m[i] = np.uint64(pats[(i // 3 + i) % len(pats)])
+        m[0] = 0
+        m[1 % rows] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        return np.minimum(m % (np.uint64(1) << np.uint64(61)), q - np.uint64(1))   # residues below q with the byte patterns intact
+
+    a_hat, b_hat = patterned(k), patterned(n)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.from_polynomials(p, a_hat, P.REPR_NTT))
+    gpk.load_rows(0, b_hat, P.REPR_NTT)
+    rows = [[int(x) for x in rng.integers(0, 1 << 64, size=n, dtype=np.uint64)] for _ in range(D)]
+    seeds = [P.api._dealer_seed(SEED, d) for d in range(D)]
+    many = P.encrypt_many(rows, gpk, seeds)
+    orc = O.Oracle(moduli, l)
+    g_hat = p.gadget_polynomial(P.REPR_NTT)
+    for d in sorted({0, 1, D // 2, D - 1}):
+        r = O.sample_cbd(seeds[d], M.DOM_R, 0, k, l, 0.5)
+        e1 = O.sample_uniform(seeds[d], M.DOM_E1, 0, k, l, 100)
+        e2 = O.sample_uniform(seeds[d], M.DOM_E2, 0, n, l, 200)
+        c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, np.array(rows[d], dtype=np.uint64), r, e1, e2)
+        assert np.array_equal(many[d].c1, c1o), f"c1 dealer {d}"
+        assert np.array_equal(many[d].c2, c2o), f"c2 dealer {d}"
+
+
 def test_multi_dealer_encrypt_l16_and_sharded():
     n, k, l, moduli = 10, 6, 16, TEST_MODULI
     full = build_params(n, k, l, moduli)
