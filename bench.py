@@ -24,6 +24,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# Kernel arguments in device memory (a documented ROCm runtime setting, read when the HIP runtime initialises, so it
+# must be in the environment before torch is imported; inherited by the ranks of a self-launch).  The encrypt
+# prologue's batch descriptor travels as kernel arguments: host-resident, every workgroup's first read of it crosses
+# PCIe -- 17.4 -> 14.5 us per launch on a box whose default is host memory (deployment notes).
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from pvw_rs_amd import workloads as W          # noqa: E402  (pure Python: geometries, modulus chain, seeds)
 
