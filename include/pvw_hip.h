@@ -29,6 +29,12 @@
  *     read-only after load and every call takes a stream + workspace from a pool.
  *   - *_device calls take device pointers and a hipStream_t (as void*; NULL =
  *     the context's own stream), enqueue asynchronously and do not synchronise.
+ *     The context's own stream is created non-blocking: it is NOT ordered against
+ *     the legacy default stream, so a caller that prepares or consumes the buffers
+ *     on the default stream (stream 0 -- also what a framework's "current stream"
+ *     usually is) must either pass a stream of its own or synchronise the device
+ *     between its work and the call (pvw_ctx_synchronize waits for the context's
+ *     stream).
  */
 #ifndef PVW_HIP_H
 #define PVW_HIP_H
