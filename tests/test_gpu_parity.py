@@ -501,6 +501,23 @@ def test_digit_gemm_extreme_matrix_bytes_against_c_oracle(n, k, l, L, D):
         assert np.array_equal(many[d].c2, c2o), f"c2 dealer {d}"
 
 
+def test_digit_gemm_repeats_are_bit_identical():
+    # The wide digit GEMM keeps LDS-DMA stages in flight across raw barriers (two wave groups half a stage apart): a
+    # misplaced wait would show as a rare wrong tile, not as a wrong algorithm.  Same call 40 times, every result
+    # equal to the first (tools/gemm_stress.py runs 2000 repeats at the bench sizes); the first is checked against
+    # the oracle by the tests above.
+    n, k, l, L, D = 600, 256, 8, 3, 40
+    p = build_params(n, k, l, M.bench_moduli(L))
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    rows = [[(d * 7919 + j) for j in range(n)] for d in range(D)]
+    seeds = [P.api._dealer_seed(SEED, d) for d in range(D)]
+    first = P.encrypt_many(rows, gpk, seeds)
+    for _ in range(40):
+        again = P.encrypt_many(rows, gpk, seeds)
+        assert all(np.array_equal(a.c1, b.c1) and np.array_equal(a.c2, b.c2) for a, b in zip(again, first))
+
+
 def test_multi_dealer_encrypt_l16_and_sharded():
     n, k, l, moduli = 10, 6, 16, TEST_MODULI
     full = build_params(n, k, l, moduli)
