@@ -55,8 +55,13 @@ static mod_t mod_make(u64 q) {
   return m;
 }
 
-/* x mod q for any 128-bit x (Barrett with the 128-bit ratio; q < 2^62). */
+/* x mod q for any 128-bit x (Barrett with the 128-bit ratio; q < 2^62).
+ * -DPVW_ORACLE_PLAIN_MOD (libpvw_oracle_plain.so): the compiler's own 128-bit remainder instead -- slow, and shares
+ * nothing with the product's Barrett step (pvw_arith.h); tests/test_oracle_c.py holds the two builds together. */
 static inline u64 reduce128(u128 x, const mod_t *m) {
+#ifdef PVW_ORACLE_PLAIN_MOD
+  return (u64)(x % (u128)m->q);
+#endif
   u64 x0 = (u64)x, x1 = (u64)(x >> 64);
   /* low 64 bits of floor(x * ratio / 2^128) */
   u128 a = (u128)x0 * m->ratio_lo;

@@ -14,7 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpvw_oracle.so")
+_PLAIN_PATH = os.path.join(_HERE, "libpvw_oracle_plain.so")   # -DPVW_ORACLE_PLAIN_MOD: 128-bit remainder, no Barrett
 _lib = None
+_plain = None
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
@@ -23,16 +25,18 @@ u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "pvw_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libpvw_oracle.so"], stdout=subprocess.DEVNULL)
+    for path in (_LIB_PATH, _PLAIN_PATH):
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(path)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(plain: bool = False):
+    """The C restatement; plain=True: the build whose every reduction is a 128-bit `%` (no Barrett step)."""
+    global _lib, _plain
+    if (_plain if plain else _lib) is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(_PLAIN_PATH if plain else _LIB_PATH)
         L.pvwo_min_primitive_root.restype = C.c_uint64
         L.pvwo_min_primitive_root.argtypes = [C.c_uint64, C.c_uint32]
         L.pvwo_ctx_create.restype = C.c_void_p
@@ -51,8 +55,11 @@ def lib():
         L.pvwo_sample_uniform.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint64, i64p]
         L.pvwo_fill_uniform_residues.argtypes = [C.c_void_p, u8p, C.c_uint32, C.c_uint32, C.c_size_t, u64p]
         L.pvwo_num_threads.restype = C.c_int
-        _lib = L
-    return _lib
+        if plain:
+            _plain = L
+        else:
+            _lib = L
+    return _plain if plain else _lib
 
 
 def _seed(seed: bytes) -> np.ndarray:
@@ -63,19 +70,20 @@ def _seed(seed: bytes) -> np.ndarray:
 class Oracle:
     """One (moduli, l) context of the C restatement."""
 
-    def __init__(self, moduli: Sequence[int], l: int, psi: Optional[Sequence[int]] = None):
+    def __init__(self, moduli: Sequence[int], l: int, psi: Optional[Sequence[int]] = None, plain: bool = False):
+        self._L = lib(plain)
         self.moduli = np.asarray(list(moduli), dtype=np.uint64)
         self.L, self.l = len(self.moduli), l
         self.psi = (np.asarray(list(psi), dtype=np.uint64) if psi is not None else
-                    np.asarray([lib().pvwo_min_primitive_root(int(q), 2 * l) for q in self.moduli],
+                    np.asarray([self._L.pvwo_min_primitive_root(int(q), 2 * l) for q in self.moduli],
                                dtype=np.uint64))
-        self._h = lib().pvwo_ctx_create(self.moduli, self.psi.ctypes.data, self.L, l)
+        self._h = self._L.pvwo_ctx_create(self.moduli, self.psi.ctypes.data, self.L, l)
         if not self._h:
             raise ValueError("pvwo_ctx_create failed")
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().pvwo_ctx_destroy(self._h)
+            self._L.pvwo_ctx_destroy(self._h)
             self._h = None
 
     @property
@@ -84,25 +92,25 @@ class Oracle:
 
     def ntt_forward(self, polys: np.ndarray) -> np.ndarray:
         out = np.ascontiguousarray(polys, dtype=np.uint64).copy()
-        lib().pvwo_ntt_forward(self._h, out.reshape(-1), out.size // self.poly)
+        self._L.pvwo_ntt_forward(self._h, out.reshape(-1), out.size // self.poly)
         return out
 
     def ntt_inverse(self, polys: np.ndarray) -> np.ndarray:
         out = np.ascontiguousarray(polys, dtype=np.uint64).copy()
-        lib().pvwo_ntt_inverse(self._h, out.reshape(-1), out.size // self.poly)
+        self._L.pvwo_ntt_inverse(self._h, out.reshape(-1), out.size // self.poly)
         return out
 
     def small_to_ntt(self, coeffs: np.ndarray) -> np.ndarray:
         coeffs = np.ascontiguousarray(coeffs, dtype=np.int64)
         count = coeffs.size // self.l
         out = np.empty(coeffs.shape[:-1] + (self.L, self.l), dtype=np.uint64)
-        lib().pvwo_small_to_ntt(self._h, coeffs.reshape(-1), count, out.reshape(-1))
+        self._L.pvwo_small_to_ntt(self._h, coeffs.reshape(-1), count, out.reshape(-1))
         return out
 
     def mac_rows(self, M: np.ndarray, v: np.ndarray, parallel: bool = True) -> np.ndarray:
         rows, k = M.shape[0], M.shape[1]
         out = np.empty((rows, self.L, self.l), dtype=np.uint64)
-        lib().pvwo_mac_rows(self._h, np.ascontiguousarray(M).reshape(-1), np.ascontiguousarray(v).reshape(-1),
+        self._L.pvwo_mac_rows(self._h, np.ascontiguousarray(M).reshape(-1), np.ascontiguousarray(v).reshape(-1),
                             rows, k, out.reshape(-1), int(parallel))
         return out
 
@@ -110,7 +118,7 @@ class Oracle:
         n, k = b_hat.shape[0], b_hat.shape[1]
         c1 = np.empty((k, self.L, self.l), dtype=np.uint64)
         c2 = np.empty((n, self.L, self.l), dtype=np.uint64)
-        lib().pvwo_encrypt(self._h, n, k, np.ascontiguousarray(a_hat).reshape(-1),
+        self._L.pvwo_encrypt(self._h, n, k, np.ascontiguousarray(a_hat).reshape(-1),
                            np.ascontiguousarray(b_hat).reshape(-1),
                            np.ascontiguousarray(g_hat, dtype=np.uint64).reshape(-1),
                            np.ascontiguousarray(scalars, dtype=np.uint64),
@@ -123,7 +131,7 @@ class Oracle:
     def keygen(self, a_hat, sk, ek):
         n, k = sk.shape[0], sk.shape[1]
         b_hat = np.empty((n, k, self.L, self.l), dtype=np.uint64)
-        lib().pvwo_keygen(self._h, n, k, np.ascontiguousarray(a_hat).reshape(-1),
+        self._L.pvwo_keygen(self._h, n, k, np.ascontiguousarray(a_hat).reshape(-1),
                           np.ascontiguousarray(sk, dtype=np.int64).reshape(-1),
                           np.ascontiguousarray(ek, dtype=np.int64).reshape(-1), b_hat.reshape(-1))
         return b_hat
@@ -131,14 +139,14 @@ class Oracle:
     def decrypt_noisy(self, sk, c1s, c2col):
         D, k = c1s.shape[0], c1s.shape[1]
         noisy = np.empty((D, self.L, self.l), dtype=np.uint64)
-        lib().pvwo_decrypt_noisy(self._h, k, np.ascontiguousarray(sk, dtype=np.int64).reshape(-1),
+        self._L.pvwo_decrypt_noisy(self._h, k, np.ascontiguousarray(sk, dtype=np.int64).reshape(-1),
                                  np.ascontiguousarray(c1s).reshape(-1),
                                  np.ascontiguousarray(c2col).reshape(-1), D, noisy.reshape(-1))
         return noisy
 
     def fill_uniform(self, seed: bytes, domain: int, index0: int, count: int) -> np.ndarray:
         out = np.empty((count, self.L, self.l), dtype=np.uint64)
-        lib().pvwo_fill_uniform_residues(self._h, _seed(seed), domain, index0, count, out.reshape(-1))
+        self._L.pvwo_fill_uniform_residues(self._h, _seed(seed), domain, index0, count, out.reshape(-1))
         return out
 
 

@@ -87,3 +87,42 @@ def test_i64_wrap_of_scalars():
     c1, c2 = orc.encrypt(a_hat, b_hat, g_hat, np.array(scalars, dtype=np.uint64),
                          np.array(s["r"]), np.array(s["e1"]), np.array(s["e2"]))
     assert np.array_equal(orc.ntt_inverse(c2), s["c2_pb"])
+
+
+@pytest.mark.parametrize("n,k,l,moduli", [(9, 7, 8, TEST_MODULI), (6, 12, 16, M.bench_moduli(5)), (5, 4, 32, EXAMPLE_MODULI)])
+def test_barrett_build_agrees_with_plain_remainder_build(n, k, l, moduli):
+    # libpvw_oracle.so reduces with a 128-bit Barrett ratio -- the same SHAPE of step as the product's pvw_arith.h;
+    # libpvw_oracle_plain.so is the same restatement with every reduction done by the compiler's 128-bit `%`.  The
+    # two must agree on everything the GPU parity tests use the oracle for (transforms, key generation, encrypt,
+    # the decrypt inner products), on residues drawn from the whole range [0, q) including its ends.
+    fast, plain = O.Oracle(moduli, l), O.Oracle(moduli, l, plain=True)
+    assert fast._L is not plain._L
+    rng = np.random.default_rng(n * 1000 + k)
+    L = len(moduli)
+    q = np.array(moduli, dtype=np.uint64)[None, None, :, None]
+
+    def residues(rows, cols):
+        m = np.stack([rng.integers(0, int(qq), size=(rows, cols, l), dtype=np.uint64) for qq in moduli], axis=2)
+        m[0, 0] = 0
+        m[-1, -1] = (q - np.uint64(1))[0, 0]
+        return m
+
+    a_hat, b_hat = residues(k, k), residues(n, k)
+    polys = residues(3, 2).reshape(6, L, l)
+    assert np.array_equal(fast.ntt_forward(polys), plain.ntt_forward(polys))
+    assert np.array_equal(fast.ntt_inverse(polys), plain.ntt_inverse(polys))
+    sk = O.sample_cbd(SEED, M.DOM_SK, 0, n * k, l, 0.5).reshape(n, k, l)
+    ek = O.sample_uniform(SEED, M.DOM_EKEY, 0, n * k, l, 100).reshape(n, k, l)
+    assert np.array_equal(fast.keygen(a_hat, sk, ek), plain.keygen(a_hat, sk, ek))
+    r = O.sample_cbd(SEED, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
+    e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
+    g_hat = fast.ntt_forward(np.stack([np.array([pow(int(M.Params(n, k, l, list(moduli)).delta), j, int(qq)) for j in range(l)],
+                                                dtype=np.uint64) for qq in moduli])[None])[0]
+    scalars = rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+    c1f, c2f = fast.encrypt(a_hat, b_hat, g_hat, scalars, r, e1, e2)
+    c1p, c2p = plain.encrypt(a_hat, b_hat, g_hat, scalars, r, e1, e2)
+    assert np.array_equal(c1f, c1p) and np.array_equal(c2f, c2p)
+    c1s = np.stack([c1f, c1p[::-1].copy()])
+    c2col = np.stack([c2f[0], c2f[-1]])
+    assert np.array_equal(fast.decrypt_noisy(sk[0], c1s, c2col), plain.decrypt_noisy(sk[0], c1s, c2col))
