@@ -3003,6 +3003,8 @@ static void launch_mac_variant(int variant, dim3 grid, hipStream_t s, const MacS
       case 21: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // timing only
       case 22: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 1><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // timing only
       case 23: if (k % 32 == 0) { mac_rows_kernel<E, 8, true, true, true, 4, 4><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
+      case 24: if (k % 32 == 0) { mac_rows_kernel<E, 16, true, true, true, 2><<<grid, dim3(128), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // two waves per item
+      case 25: if (k % 16 == 0) { mac_rows_kernel<E, 8, true, true, true, 2><<<grid, dim3(128), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;
       case 50: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 2, false, 1><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // XCD-contiguous items
       case 51: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 2, true, 1><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;    // + stamps
       case 40: if (k % 64 == 0) { mac_rows_kernel<E, 16, true, true, true, 4, 1, 2, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, mods, k, L); return; } break;   // default schedule + stamps

@@ -37,10 +37,10 @@ def test_tuning_build_is_selected():
 ])
 def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
     # every streaming schedule of mac_rows (PVW_MAC_VARIANT) computes the same c1, c2 (encryption.rs:158,177-200)
-    # 0-19 schedules of the one-workgroup-per-item kernel, 20 / 23 the same with a register cap, 30 / 31 the
+    # 0-19 schedules of the one-workgroup-per-item kernel, 20 / 23 the same with a register cap, 24 / 25 two waves per item, 30 / 31 the
     # persistent kernel (21 / 22 are timing ablations with wrong results by design and are not walked)
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for variant in list(range(0, 21)) + [23, 30, 31]:
+    for variant in list(range(0, 21)) + [23, 24, 25, 30, 31]:
         monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
         ct = run()
         assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
