@@ -216,7 +216,15 @@ def main():
     alg_bytes = 8 * L * l * (n_per * k + rows_a * k + nv * (n_per + rows_a + k))
     achieved = alg_bytes / mac_avg_s / 1e9 if mac_avg_s > 0 else 0.0
 
-    tr = measured_traffic(args.config or "c3", "mac_rows_kernel")
+    # single-dealer launches stream the matrices from their 61-bit packed copy when the geometry qualifies (the rule of
+    # pvw_capi.hip, ensure_packed): the algorithmic bytes stay SURVEY 8d's 8 bytes per residue, the bytes the kernel
+    # actually has to read are reported next to them
+    packed = (Dm == 0 and l <= 16 and k % 256 == 0 and all(q < (1 << 61) for q in moduli)
+              and not (os.environ.get("PVW_HIP_LIBRARY") == "tuning"
+                       and (os.environ.get("PVW_MAC_PACKED") == "0" or os.environ.get("PVW_MAC_VARIANT", "0") != "0")))
+    mac_kernel = "mac_rows_packed_kernel" if packed else "mac_rows_kernel"
+    streamed_bytes = (8 * L * l * ((n_per * k + rows_a * k) * 61 // 64 + nv * (n_per + rows_a + k))) if packed else alg_bytes
+    tr = measured_traffic(args.config or "c3", mac_kernel)
     out = {
         "metric": "parties/s for n-party encrypt (pvw::crypto::encrypt); achieved HBM GB/s vs peak",
         "value": value, "unit": "parties/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -226,10 +234,14 @@ def main():
                    "rns_limbs": L, "q_bits": int(params.q_total().bit_length()), "randomness": "seed (ChaCha8), on device", "dealers_per_step": max(Dm, 1),
                    "sharding": f"party-sharded x{world}, A-hat broadcast once, no data-path collective",
                    "world_size_observed": world, "backend": (os.environ.get("PVW_BENCH_BACKEND", "nccl") if world > 1 else None)},
-        "roofline": {"bound": "hbm", "kernel": "mac_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": mac_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                      "traffic_source": (tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)") if tr else None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": mac_avg_s * 1e6,
+                     "algorithmic_bytes_per_launch": alg_bytes, "streamed_bytes_per_launch": streamed_bytes,
+                     "frac_of_streamed_bytes": (streamed_bytes / mac_avg_s / 1e9 / HBM_PEAK_GBS) if mac_avg_s > 0 else 0.0,
+                     "packing": ("matrix residues stored at 61 of 64 bits (mac_rows_packed_kernel): `achieved` / `frac` count the algorithmic "
+                                 "8 bytes per residue, `frac_of_streamed_bytes` the bytes the kernel reads") if packed else None,
+                     "avg_launch_us": mac_avg_s * 1e6,
                      "launches_timed": mac_launches},
         "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},
     }

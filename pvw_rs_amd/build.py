@@ -63,6 +63,8 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = True, shipp
             extra.append("-DPVW_GEMM_ABLATE=" + os.environ["PVW_GEMM_ABLATE"])
         if os.environ.get("PVW_GEMM_RPW"):             # row tiles per wave of the digit GEMM (experiment)
             extra.append("-DPVW_GEMM_RPW=" + os.environ["PVW_GEMM_RPW"])
+        if os.environ.get("PVW_PACKED_WPC"):           # workgroups per CU the packed mac_rows is register-allocated for (experiment)
+            extra.append("-DPVW_PACKED_WPC=" + os.environ["PVW_PACKED_WPC"])
         jobs.append((LIB_TUNING,) + _build_one(LIB_TUNING, extra, "_tuning", verbose))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     for lib, objs, procs in jobs:

@@ -187,6 +187,12 @@ struct pvw_ctx {
   u64* xmA = nullptr;
   u64* xmB = nullptr;
   bool xm_valid = false;
+  // packed copies (61 bits per residue) for the single-dealer mac_rows: built lazily by the first encrypt when the
+  // geometry allows it and the memory is there, dropped whenever A or B changes (launch_pack61)
+  u64* pkA = nullptr;
+  u64* pkB = nullptr;
+  bool pk_valid = false;
+  bool pk_off = false;      // the copy does not fit / the geometry does not qualify: decided once per matrix state
   bool crs_loaded = false;
   u32 num_keys = 0;
   hipStream_t stream = nullptr;
@@ -599,6 +605,8 @@ int32_t pvw_ctx_destroy(pvw_ctx* c) {
     hipFree(c->dB);
     hipFree(c->xmA);
     hipFree(c->xmB);
+    hipFree(c->pkA);
+    hipFree(c->pkB);
     hipFree(c->d_tables);
     hipFree(c->d_dec);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -816,6 +824,36 @@ static int32_t ensure_xm(pvw_ctx* c, hipStream_t s) {
   return PVW_OK;
 }
 
+// packed copies of the resident A-hat / B-hat sections for mac_rows (pvw_kernels.hip, mac_rows_packed_kernel): needs
+// l <= 16, k a multiple of 256, every modulus below 2^61, and room for a second copy of the matrices.  Returns false
+// (and remembers it) when the plain tiled matrices are to be streamed instead.
+static bool ensure_packed(pvw_ctx* c, hipStream_t s) {
+  // tuning build: A/B runs against the unpacked stream, and an explicit schedule of the unpacked kernel is honoured
+  if (PVW_ENV_INT("PVW_MAC_PACKED", 1) == 0 || PVW_ENV_INT("PVW_MAC_VARIANT", 0) != 0) return false;
+  std::lock_guard<std::mutex> g(c->init_mu);
+  if (c->pk_valid) return true;
+  if (c->pk_off) return false;
+  c->pk_off = true;                                     // until proven otherwise
+  if (c->l > 16 || c->k % 256 != 0) return false;
+  for (u64 q : c->moduli)
+    if (q >> 61) return false;
+  const u32 rA = c->rowsA(), rB = c->rowsB();
+  const size_t wa = packed_words(rA, c->k, c->L, c->l), wb = packed_words(rB, c->k, c->L, c->l);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  const size_t have = (c->pkA ? 0 : wa * 8) + (c->pkB ? 0 : wb * 8);
+  if (free_b < have + ((size_t)4 << 30)) return false;  // leave room for the callers' own buffers
+  if (!c->pkA && wa && hipMalloc((void**)&c->pkA, wa * 8) != hipSuccess) return false;
+  if (!c->pkB && wb && hipMalloc((void**)&c->pkB, wb * 8) != hipSuccess) return false;
+  ProfScope ps(c, "pack61", s);
+  if (launch_pack61(c->dA, c->pkA, rA, c->k, c->L, c->l, s) != hipSuccess) return false;
+  if (launch_pack61(c->dB, c->pkB, rB, c->k, c->L, c->l, s) != hipSuccess) return false;
+  if (hipStreamSynchronize(s) != hipSuccess) return false;
+  c->pk_valid = true;
+  c->pk_off = false;
+  return true;
+}
+
 static int32_t check_repr(uint32_t repr) {
   if (repr != PVW_REPR_POWER && repr != PVW_REPR_NTT) return fail(PVW_ERR_INVALID_FORMAT, "unknown representation");
   return PVW_OK;
@@ -825,7 +863,7 @@ int32_t pvw_load_crs(pvw_ctx* c, const uint64_t* a, uint32_t repr) {
   if (!c || !a) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(check_repr(repr));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false;
+  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   PVW_TRY(load_rows_host(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, a, repr));
   c->crs_loaded = true;
@@ -835,7 +873,7 @@ int32_t pvw_load_crs_device(pvw_ctx* c, const uint64_t* d_a, uint32_t repr, void
   if (!c || !d_a) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(check_repr(repr));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false;
+  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   PVW_TRY(load_rows_device(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, d_a, repr, s));
@@ -845,7 +883,7 @@ int32_t pvw_load_crs_device(pvw_ctx* c, const uint64_t* d_a, uint32_t repr, void
 int32_t pvw_crs_generate(pvw_ctx* c, const uint8_t seed[32]) {
   if (!c || !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false;
+  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   {
     ProfScope ps(c, "fill_uniform", c->stream);
@@ -979,7 +1017,7 @@ int32_t pvw_load_pk(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t* b, uin
   PVW_TRY(check_repr(repr));
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false;
+  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   PVW_TRY(load_rows_host(c, c->dB, c->party_lo, c->party_hi, lo, hi, b, repr));
   if (hi > c->num_keys) c->num_keys = hi;                                          // public_key.rs:245-247
@@ -990,7 +1028,7 @@ int32_t pvw_load_pk_device(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t*
   PVW_TRY(check_repr(repr));
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false;
+  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   PVW_TRY(load_rows_device(c, c->dB, c->party_lo, c->party_hi, lo, hi, d_b, repr, s));
@@ -1000,7 +1038,7 @@ int32_t pvw_load_pk_device(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t*
 int32_t pvw_pk_fill_uniform(pvw_ctx* c, const uint8_t seed[32]) {
   if (!c || !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false;
+  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   {
     ProfScope ps(c, "fill_uniform", c->stream);
@@ -1258,6 +1296,7 @@ static int32_t fill_encrypt_jobs(pvw_ctx* c, PrologueBatch& pb, u32 slot, u32 /*
 static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, const pvw_randomness_t* rnd,
                                u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
   const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
+  const bool packed = ensure_packed(c, s);                  // first call after a matrix change: builds the packed copies
   PrologueBatch pb{};
   PVW_TRY(fill_encrypt_jobs(c, pb, 0, 0, rnd, d_scalars, w->rhat, d_c1, d_c2));
   pb.njobs = (u32)PVW_ENV_INT("PVW_PROLOGUE_JOBS", 3);     // tuning build, timing experiment (results wrong): 1 = r only
@@ -1267,8 +1306,13 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
   }
   {
     ProfScope ps(c, "mac_rows", s);
-    MacSection a{c->dA, d_c1, d_c1, rA, 0}, b{c->dB, d_c2, d_c2, rB, 0};
-    PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s, w->counters));         // crs.rs:188-201, encryption.rs:177-200
+    if (packed) {
+      MacSection a{c->pkA, d_c1, d_c1, rA, 0}, b{c->pkB, d_c2, d_c2, rB, 0};
+      PVW_HIP(launch_mac_rows_packed(a, b, w->rhat, c->dt, k, L, l, s));             // the same sums over the 61-bit packed copy
+    } else {
+      MacSection a{c->dA, d_c1, d_c1, rA, 0}, b{c->dB, d_c2, d_c2, rB, 0};
+      PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s, w->counters));       // crs.rs:188-201, encryption.rs:177-200
+    }
   }
   if (out_repr == PVW_REPR_POWER) {
     ProfScope ps(c, "intt", s);
@@ -2005,7 +2049,7 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   if (!ek && !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "either explicit key errors or a seed is required");
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false;
+  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
   if (!c->crs_loaded) return fail(PVW_ERR_CRS, "CRS not loaded");
   if (c->rowsA() != c->k) return fail(PVW_ERR_KEY_GENERATION, "key generation needs the full CRS on this context");
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));

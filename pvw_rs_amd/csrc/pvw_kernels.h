@@ -117,6 +117,16 @@ struct PrologueBatch {   // sizeof must stay below the 4 KiB kernel-argument lim
 };
 hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s);
 
+// the same over the PACKED copy of the sections (61 bits per residue; MacSection::M = the packed copy): l <= 16,
+// k a multiple of 256, every modulus below 2^61.  launch_pack61 builds that copy from the tiled matrix:
+// packed_words(rows) u64 per section.
+hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L,
+                                  u32 ell, hipStream_t s);
+hipError_t launch_pack61(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s);
+inline size_t packed_words(u32 rows, u32 k, u32 L, u32 ell) {
+  const u32 R = 128 / ell;
+  return (size_t)((rows + R - 1) / R) * L * (k / 64 * 61) * 128;
+}
 // NV (<= 4) vectors sharing one pass over the tiled matrix (mac_rows_multi)
 struct MultiVec {
   const u64* vhat;      // [nv][L][k][l]

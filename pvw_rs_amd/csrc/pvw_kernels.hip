@@ -229,6 +229,155 @@ __global__ __launch_bounds__(NW * 64, WPE) void mac_rows_kernel(MacSection sa, M
 }
 
 // ------------------------------------------------------------------------------------
+// mac_rows over the PACKED copy of the tiled matrix.  mac_rows is bound by the bytes it streams, and a residue of a
+// 61-bit modulus carries 61 bits in an 8-byte word: the packed copy stores, for every (row block, limb, lane), the
+// lane's residue pairs (x_j, y_j), j = 0..k-1, as ONE bit stream of 122 bits per j, cut into 16-byte chunks;
+// chunk c of the 64 lanes is 1 KiB contiguous, so the loads are exactly mac_rows' (global_load_dwordx4 nt, 1 KiB
+// per wave-instruction) -- there are just 61 of them per 64 j instead of 64 (-4.7 % bytes).  64 j are 61 chunks
+// exactly, so with k a multiple of 256 every wave owns whole periods (j in [w k/4, (w+1) k/4)) and every shift
+// amount is a compile-time constant: the period is unrolled as 4 groups of 16 j, each living in 16 chunks (the last
+// chunk of a group is the first of the next and is carried in registers, not loaded again), 15-16 chunks in
+// flight per wave while the previous group is multiplied.  Unpacking is two funnel shifts and a mask per residue on
+// a VALU that the quarter-rate v_mad_u64_u32 stream leaves half idle.  Same lazy accumulation, same epilogue, same
+// results as mac_rows_kernel.  Built lazily by the C ABI (pack61_kernel) next to the tiled matrix, which every
+// other consumer keeps using.
+// ------------------------------------------------------------------------------------
+constexpr u64 PVW_MASK61 = (1ull << 61) - 1;
+#ifndef PVW_PACKED_WPC
+#define PVW_PACKED_WPC 2                                  // workgroups per CU the register allocation aims at
+#endif
+__device__ __forceinline__ u64 pk_word(const v2u64 (&a)[16], int idx) { return (idx & 1) ? a[idx >> 1].y : a[idx >> 1].x; }
+// the 61 bits at bit offset `bit` of the 2048-bit window a[0..15] (bit is a constant after unrolling)
+__device__ __forceinline__ u64 pk_get61(const v2u64 (&a)[16], int bit) {
+  const int idx = bit >> 6, sh = bit & 63;
+  u64 v = pk_word(a, idx) >> sh;
+  if (sh > 3) v |= pk_word(a, idx + 1) << (64 - sh);
+  return v & PVW_MASK61;
+}
+template <int ELL>
+__global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
+                                                               const Mod* __restrict__ mods, u32 k, u32 L) {
+  constexpr int HALF = ELL / 2, R = 128 / ELL, JC = 64, NW = 4;
+  static_assert(ELL <= 16, "one period of 64 j per r-hat slab");
+  __shared__ v2u64 lds[NW * JC * HALF];
+  const u32 item = blockIdx.x;
+  const u32 limb = item % L, rbg = item / L;
+  const bool in_a = rbg < sa.row_blocks;
+  const u32 rb = in_a ? rbg : rbg - sa.row_blocks;
+  const u64* __restrict__ Pk = in_a ? sa.M : sb.M;           // the PACKED copy of the section
+  const u64* addend = in_a ? sa.addend : sb.addend;
+  u64* out = in_a ? sa.out : sb.out;
+  const u32 nrows = in_a ? sa.nrows : sb.nrows;
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 sp = lane % HALF, rho = lane / HALF;
+  const u32 kq = k / NW, periods = kq / 64;                   // the launcher guarantees k % 256 == 0
+  const u32 chunks = k / 64 * 61;                             // per (row block, limb)
+  const v2u64* Pp = reinterpret_cast<const v2u64*>(Pk) + (((size_t)rb * L + limb) * chunks + (size_t)wave * periods * 61) * 64 + lane;
+  const v2u64* rp = reinterpret_cast<const v2u64*>(rhat + (size_t)limb * k * ELL) + (size_t)wave * kq * HALF;
+  v2u64* lw = lds + wave * (JC * HALF);
+  const u32 out_row = rb * R + rho;
+  const size_t out_o = (((size_t)out_row * L + limb) * ELL) / 2 + sp;
+  v2u64 add_pf = (v2u64){0, 0};
+  if (wave == 0 && addend && out_row < nrows) add_pf = reinterpret_cast<const v2u64*>(addend)[out_o];
+  Acc a0, a1;
+  acc_zero(a0);
+  acc_zero(a1);
+  auto ldc = [&](u32 c) -> v2u64 { return __builtin_nontemporal_load(Pp + (size_t)c * 64); };
+  v2u64 xa[16], xb[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) xa[u] = ldc(u);                // group 0 of the first period
+  for (u32 pd = 0; pd < periods; ++pd) {
+    const u32 cb = pd * 61;
+    // this period's r-hat slab: 64 j x HALF sixteen-byte elements, HALF per lane
+    __builtin_amdgcn_wave_barrier();
+    constexpr int RN = JC * HALF / 64;
+    v2u64 rv[RN];
+#pragma unroll
+    for (int x = 0; x < RN; ++x) rv[x] = rp[(size_t)pd * 64 * HALF + lane + 64 * x];
+#pragma unroll
+    for (int x = 0; x < RN; ++x) lw[lane + 64 * x] = rv[x];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // group g: j = 16 g .. 16 g + 15 of the period, bits 32 g + 122 jj of the window cur[] = chunks 15 g .. 15 g + 15;
+    // nxt[1..15] = chunks 15 g + 16 .. 15 g + 30 are requested first, nxt[0] is cur[15]
+    auto group = [&](const int g, v2u64 (&cur)[16], v2u64 (&nxt)[16]) {
+      if (g < 3) {
+#pragma unroll
+        for (int u = 1; u < 16; ++u) nxt[u] = ldc(cb + 15 * (g + 1) + u);
+      } else if (pd + 1 < periods) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) nxt[u] = ldc(cb + 61 + u);   // group 0 of the next period
+      }
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int bit = 32 * g + 122 * jj;
+        const u64 xv = pk_get61(cur, bit), yv = pk_get61(cur, bit + 61);
+        const v2u64 r = lw[(16 * g + jj) * HALF + sp];
+        acc_mac_dev(a0, xv, r.x);
+        acc_mac_dev(a1, yv, r.y);
+      }
+      if (g < 3) nxt[0] = cur[15];
+    };
+    group(0, xa, xb);
+    group(1, xb, xa);
+    group(2, xa, xb);
+    group(3, xb, xa);                                          // leaves the next period's group 0 in xa
+  }
+  const Mod m = mods[limb];
+  v2u64 part;
+  part.x = acc_reduce(a0, m);
+  part.y = acc_reduce(a1, m);
+  __syncthreads();
+  lds[wave * 64 + lane] = part;
+  __syncthreads();
+  if (wave == 0 && out_row < nrows) {
+    v2u64 sres = lds[lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const v2u64 t = lds[w * 64 + lane];
+      sres.x = addmod(sres.x, t.x, m.q);
+      sres.y = addmod(sres.y, t.y, m.q);
+    }
+    if (addend) {
+      sres.x = addmod(sres.x, add_pf.x, m.q);
+      sres.y = addmod(sres.y, add_pf.y, m.q);
+    }
+    reinterpret_cast<v2u64*>(out)[out_o] = sres;
+  }
+}
+
+// tiled matrix -> packed copy: one thread per (row block, limb, lane) walks its k residue pairs and emits the bit
+// stream in 16-byte chunks (reads and writes are both 1 KiB per wave and step; load-time only)
+__global__ __launch_bounds__(256) void pack61_kernel(const u64* __restrict__ M, u64* __restrict__ P, u32 k, size_t items) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t item = t >> 6;
+  const u32 lane = (u32)(t & 63);
+  if (item >= items) return;
+  const v2u64* src = reinterpret_cast<const v2u64*>(M) + item * (size_t)k * 64 + lane;
+  v2u64* dst = reinterpret_cast<v2u64*>(P) + item * (size_t)(k / 64 * 61) * 64 + lane;
+  u64 lo = 0, hi = 0, pend = 0;      // bit buffer (lo, hi), `nb` bits used; pend = the even word of the chunk being filled
+  u32 nb = 0, words = 0;
+  auto push = [&](u64 v) {
+    lo |= v << nb;
+    if (nb > 3) hi |= v >> (64 - nb);
+    nb += 61;
+    if (nb >= 64) {
+      if (words & 1) dst[(size_t)(words >> 1) * 64] = (v2u64){pend, lo};
+      else pend = lo;
+      ++words;
+      lo = hi;
+      hi = 0;
+      nb -= 64;
+    }
+  };
+  for (u32 j = 0; j < k; ++j) {
+    const v2u64 v = src[(size_t)j * 64];
+    push(v.x & PVW_MASK61);
+    push(v.y & PVW_MASK61);
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // mac_rows, persistent form.  The grid is sized to what the chip holds at once (workgroups per CU x CUs) and every
 // workgroup walks work items (row block, limb), so a slot never idles while the dispatcher tears one workgroup
 // down and sets the next one up, the epilogue of an item (Barrett, cross-wave sum, addend, store) runs UNDER the
@@ -3062,6 +3211,28 @@ hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* 
   const u32 blocks = (sa.row_blocks + sb.row_blocks) * L;
   if (blocks == 0) return hipSuccess;
   PVW_DISPATCH_ELL(ell, launch_mac_variant<E>(mac_variant(), dim3(blocks), s, sa, sb, rhat, t.mods, k, L, counters));
+  return hipGetLastError();
+}
+
+hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L,
+                                  u32 ell, hipStream_t s) {
+  if (ell > 16 || k % 256 != 0) return hipErrorInvalidValue;
+  const u32 R = 128 / ell;
+  MacSection sa = a, sb = b;
+  sa.row_blocks = (a.nrows + R - 1) / R;
+  sb.row_blocks = (b.nrows + R - 1) / R;
+  const u32 blocks = (sa.row_blocks + sb.row_blocks) * L;
+  if (blocks == 0) return hipSuccess;
+  if (ell == 8) mac_rows_packed_kernel<8><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+  else mac_rows_packed_kernel<16><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+  return hipGetLastError();
+}
+hipError_t launch_pack61(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  if (k % 64 != 0) return hipErrorInvalidValue;
+  const u32 R = 128 / ell;
+  const size_t items = (size_t)((rows + R - 1) / R) * L;
+  pack61_kernel<<<dim3((u32)((items * 64 + 255) / 256)), dim3(256), 0, s>>>(M, P, k, items);
   return hipGetLastError();
 }
 

@@ -334,6 +334,9 @@ def test_ragged_geometries_against_c_oracle(n, k, l, L):
 
 
 MAC_SCHEDULE_CASES = [(40, 256, 8, 3), (21, 128, 16, 2), (9, 64, 8, 2), (5, 24, 8, 2)]
+# geometries that qualify for the 61-bit packed stream (l <= 16, k a multiple of 256): one and two periods per wave,
+# ragged row blocks, l = 8 and 16, three periods (k = 768)
+MAC_PACKED_CASES = [(40, 256, 8, 3), (19, 512, 16, 2), (133, 512, 8, 2), (9, 768, 8, 2), (70, 256, 16, 3)]
 
 
 def mac_rows_case(n, k, l, L):
@@ -358,6 +361,48 @@ def test_mac_rows_shape_selected_schedule_agrees_with_c_oracle(n, k, l, L):
     # the schedule the shipped library picks by shape (every other one: tests/test_gpu_tuning.py)
     run, c1o, c2o = mac_rows_case(n, k, l, L)
     ct = run()
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+
+
+@pytest.mark.parametrize("n,k,l,L", MAC_PACKED_CASES)
+def test_mac_rows_over_the_packed_matrix_agrees_with_c_oracle(n, k, l, L):
+    # mac_rows_packed_kernel: the tiled matrix is streamed from a 61-bit-per-residue copy (pack61_kernel); twice, so
+    # that the second call reuses the copy, then after the public key has changed (the copy must be rebuilt)
+    run, c1o, c2o = mac_rows_case(n, k, l, L)
+    for _ in range(2):
+        ct = run()
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+
+
+def test_packed_matrix_follows_key_changes_and_wide_moduli_fall_back():
+    n, k, l = 24, 256, 8
+    moduli = M.bench_moduli(2)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(SEED, M.DOM_CRS, 0, k * k).reshape(k, k, 2, l)
+    scalars = np.arange(1, n + 1, dtype=np.uint64)
+    r = O.sample_cbd(SEED, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
+    e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
+    g_hat = p.gadget_polynomial(P.REPR_NTT)
+    for seed in (SEED, bytes([0x77]) * 32, SEED):           # every refill invalidates the packed copy
+        gpk.fill_uniform(seed)
+        b_hat = orc.fill_uniform(seed, M.DOM_PK, 0, n * k).reshape(n, k, 2, l)
+        c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, scalars, r, e1, e2)
+        ct = P.encrypt(scalars, gpk, SEED)
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+    # a modulus of 62 bits does not fit the 61-bit stream: the unpacked kernel must serve it
+    wide = primes_1mod(64, 2, top=(1 << 62) - 64)        # top must be a multiple of the step
+    assert all(q >> 61 for q in wide)
+    p2 = build_params(n, k, l, wide)
+    gpk2 = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p2, SEED))
+    gpk2.fill_uniform(SEED)
+    orc2 = O.Oracle(wide, l)
+    a2 = orc2.fill_uniform(SEED, M.DOM_CRS, 0, k * k).reshape(k, k, 2, l)
+    b2 = orc2.fill_uniform(SEED, M.DOM_PK, 0, n * k).reshape(n, k, 2, l)
+    c1o, c2o = orc2.encrypt(a2, b2, p2.gadget_polynomial(P.REPR_NTT), scalars, r, e1, e2)
+    ct = P.encrypt(scalars, gpk2, SEED)
     assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
 
 

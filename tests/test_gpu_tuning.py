@@ -46,6 +46,17 @@ def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
         assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
 
 
+@pytest.mark.parametrize("n,k,l,L", T.MAC_PACKED_CASES)
+def test_mac_rows_packed_and_unpacked_streams_agree(n, k, l, L, monkeypatch):
+    # PVW_MAC_PACKED=0: the geometries the shipped library streams from the 61-bit packed copy, served by the
+    # unpacked mac_rows_kernel instead -- same ciphertexts, both equal to the oracle's
+    run, c1o, c2o = T.mac_rows_case(n, k, l, L)
+    for packed in ("1", "0"):
+        monkeypatch.setenv("PVW_MAC_PACKED", packed)
+        ct = run()
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), packed
+
+
 @pytest.mark.parametrize("k,l,L,D", T.DECRYPT_SHAPE_CASES)
 def test_decrypt_mac_launch_shapes_agree_with_c_oracle(k, l, L, D, monkeypatch):
     # every launch shape of decrypt_party_value's <sk, c1> (decryption.rs:257-274) gives the oracle's noisy
