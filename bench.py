@@ -288,8 +288,9 @@ def main():
             if sec.value > 0:
                 gbps = nbytes.value / sec.value / 1e9
                 out["roofline"]["read_probe"] = {"GBps": gbps, "bytes_per_pass": nbytes.value,
-                                                 "mac_rows_over_probe": achieved / gbps,
-                                                 "note": "same loads as mac_rows (1-KiB tiles, 16 B/lane, nt, 16 in flight per wave), xor instead of the modular MAC; libpvw_hip_tuning.so"}
+                                                 "mac_rows_over_probe": (streamed_bytes / mac_avg_s / 1e9) / gbps if mac_avg_s > 0 else None,
+                                                 "note": "mac_rows' loads (1-KiB tiles, 16 B/lane, nt, 16 in flight per wave) over the UNPACKED tiled B-hat with an xor instead of the "
+                                                         "modular MAC; mac_rows_over_probe compares the bytes mac_rows actually streams per second with it; libpvw_hip_tuning.so"}
             del pt
         except Exception as e:                 # the tuning build is optional equipment
             out["roofline"]["read_probe"] = {"error": str(e)[:200]}
