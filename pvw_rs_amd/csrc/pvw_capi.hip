@@ -191,6 +191,7 @@ struct pvw_ctx {
   // geometry allows it and the memory is there, dropped whenever A or B changes (launch_pack61)
   u64* pkA = nullptr;
   u64* pkB = nullptr;
+  u32* pk_flag = nullptr;   // device word: set by pack61_kernel when a matrix word exceeds 61 bits
   bool pk_valid = false;
   bool pk_off = false;      // the copy does not fit / the geometry does not qualify: decided once per matrix state
   bool crs_loaded = false;
@@ -607,6 +608,7 @@ int32_t pvw_ctx_destroy(pvw_ctx* c) {
     hipFree(c->xmB);
     hipFree(c->pkA);
     hipFree(c->pkB);
+    hipFree(c->pk_flag);
     hipFree(c->d_tables);
     hipFree(c->d_dec);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -845,10 +847,17 @@ static bool ensure_packed(pvw_ctx* c, hipStream_t s) {
   if (free_b < have + ((size_t)4 << 30)) return false;  // leave room for the callers' own buffers
   if (!c->pkA && wa && hipMalloc((void**)&c->pkA, wa * 8) != hipSuccess) return false;
   if (!c->pkB && wb && hipMalloc((void**)&c->pkB, wb * 8) != hipSuccess) return false;
-  ProfScope ps(c, "pack61", s);
-  if (launch_pack61(c->dA, c->pkA, rA, c->k, c->L, c->l, s) != hipSuccess) return false;
-  if (launch_pack61(c->dB, c->pkB, rB, c->k, c->L, c->l, s) != hipSuccess) return false;
+  if (!c->pk_flag && hipMalloc((void**)&c->pk_flag, sizeof(u32)) != hipSuccess) return false;
+  if (hipMemsetAsync(c->pk_flag, 0, sizeof(u32), s) != hipSuccess) return false;
+  {
+    ProfScope ps(c, "pack61", s);
+    if (launch_pack61(c->dA, c->pkA, rA, c->k, c->L, c->l, c->pk_flag, s) != hipSuccess) return false;
+    if (launch_pack61(c->dB, c->pkB, rB, c->k, c->L, c->l, c->pk_flag, s) != hipSuccess) return false;
+  }
+  u32 wide = 1;
+  if (hipMemcpyAsync(&wide, c->pk_flag, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return false;
   if (hipStreamSynchronize(s) != hipSuccess) return false;
+  if (wide) return false;                               // residues were loaded unreduced: stream the tiled matrices as they are
   c->pk_valid = true;
   c->pk_off = false;
   return true;

@@ -122,7 +122,8 @@ hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L
 // packed_words(rows) u64 per section.
 hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L,
                                   u32 ell, hipStream_t s);
-hipError_t launch_pack61(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s);
+// *wide_flag (device word, zeroed by the caller) is set when a matrix word does not fit 61 bits: the copy is then unusable
+hipError_t launch_pack61(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, u32* wide_flag, hipStream_t s);
 inline size_t packed_words(u32 rows, u32 k, u32 L, u32 ell) {
   const u32 R = 128 / ell;
   return (size_t)((rows + R - 1) / R) * L * (k / 64 * 61) * 128;

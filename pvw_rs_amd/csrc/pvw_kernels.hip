@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed_kernel(Ma
 
 // tiled matrix -> packed copy: one thread per (row block, limb, lane) walks its k residue pairs and emits the bit
 // stream in 16-byte chunks (reads and writes are both 1 KiB per wave and step; load-time only)
-__global__ __launch_bounds__(256) void pack61_kernel(const u64* __restrict__ M, u64* __restrict__ P, u32 k, size_t items) {
+__global__ __launch_bounds__(256) void pack61_kernel(const u64* __restrict__ M, u64* __restrict__ P, u32 k, size_t items,
+                                                      u32* __restrict__ wide_flag) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t item = t >> 6;
   const u32 lane = (u32)(t & 63);
@@ -370,11 +371,15 @@ __global__ __launch_bounds__(256) void pack61_kernel(const u64* __restrict__ M, 
       nb -= 64;
     }
   };
+  u64 seen = 0;
   for (u32 j = 0; j < k; ++j) {
     const v2u64 v = src[(size_t)j * 64];
+    seen |= v.x | v.y;
     push(v.x & PVW_MASK61);
     push(v.y & PVW_MASK61);
   }
+  // a word that does not fit 61 bits (a caller loaded unreduced data): the copy must not be used
+  if (seen >> 61) atomicOr(wide_flag, 1u);
 }
 
 // ------------------------------------------------------------------------------------
@@ -3227,12 +3232,12 @@ hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, cons
   else mac_rows_packed_kernel<16><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
   return hipGetLastError();
 }
-hipError_t launch_pack61(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s) {
+hipError_t launch_pack61(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, u32* wide_flag, hipStream_t s) {
   if (rows == 0) return hipSuccess;
   if (k % 64 != 0) return hipErrorInvalidValue;
   const u32 R = 128 / ell;
   const size_t items = (size_t)((rows + R - 1) / R) * L;
-  pack61_kernel<<<dim3((u32)((items * 64 + 255) / 256)), dim3(256), 0, s>>>(M, P, k, items);
+  pack61_kernel<<<dim3((u32)((items * 64 + 255) / 256)), dim3(256), 0, s>>>(M, P, k, items, wide_flag);
   return hipGetLastError();
 }
 

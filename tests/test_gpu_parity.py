@@ -392,6 +392,16 @@ def test_packed_matrix_follows_key_changes_and_wide_moduli_fall_back():
         c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, scalars, r, e1, e2)
         ct = P.encrypt(scalars, gpk, SEED)
         assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+    # residues loaded UNREDUCED (r + q needs 62 bits): the copy would truncate them, so it must not be used
+    b_hat = orc.fill_uniform(SEED, M.DOM_PK, 0, n * k).reshape(n, k, 2, l)
+    unreduced = b_hat.copy()
+    unreduced[3, 5] += np.array(moduli, dtype=np.uint64)[:, None]
+    unreduced[n - 1, k - 1, 1, l - 1] += np.uint64(moduli[1])
+    assert (unreduced >> np.uint64(61)).any()
+    gpk.load_rows(0, unreduced, P.REPR_NTT)
+    c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, scalars, r, e1, e2)
+    ct = P.encrypt(scalars, gpk, SEED)
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
     # a modulus of 62 bits does not fit the 61-bit stream: the unpacked kernel must serve it
     wide = primes_1mod(64, 2, top=(1 << 62) - 64)        # top must be a multiple of the step
     assert all(q >> 61 for q in wide)
