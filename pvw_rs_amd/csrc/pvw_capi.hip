@@ -831,7 +831,7 @@ static int32_t ensure_xm(pvw_ctx* c, hipStream_t s) {
 // (and remembers it) when the plain tiled matrices are to be streamed instead.
 static bool ensure_packed(pvw_ctx* c, hipStream_t s) {
   // tuning build: A/B runs against the unpacked stream, and an explicit schedule of the unpacked kernel is honoured
-  if (PVW_ENV_INT("PVW_MAC_PACKED", 1) == 0 || PVW_ENV_INT("PVW_MAC_VARIANT", 0) != 0) return false;
+  if (PVW_ENV_INT("PVW_MAC_PACKED", 1) == 0 || (PVW_ENV_INT("PVW_MAC_VARIANT", 0) != 0 && PVW_ENV_INT("PVW_MAC_VARIANT", 0) != 44)) return false;
   std::lock_guard<std::mutex> g(c->init_mu);
   if (c->pk_valid) return true;
   if (c->pk_off) return false;

@@ -254,9 +254,17 @@ __device__ __forceinline__ u64 pk_get61(const v2u64 (&a)[16], int bit) {
   if (sh > 3) v |= pk_word(a, idx + 1) << (64 - sh);
   return v & PVW_MASK61;
 }
-template <int ELL>
+template <int ELL, bool STAMP = false>
 __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
                                                                const Mod* __restrict__ mods, u32 k, u32 L) {
+#if PVW_TUNING
+  if constexpr (STAMP) {
+    if (threadIdx.x == 0 && blockIdx.x < PVW_STAMP_MAX) {
+      g_stamp_buf[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+      g_stamp_hw[blockIdx.x] = (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 28) | (blockIdx.x & 0x0fffffffu);
+    }
+  }
+#endif
   constexpr int HALF = ELL / 2, R = 128 / ELL, JC = 64, NW = 4;
   static_assert(ELL <= 16, "one period of 64 j per r-hat slab");
   __shared__ v2u64 lds[NW * JC * HALF];
@@ -344,6 +352,11 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed_kernel(Ma
     }
     reinterpret_cast<v2u64*>(out)[out_o] = sres;
   }
+#if PVW_TUNING
+  if constexpr (STAMP) {
+    if (threadIdx.x == 0 && blockIdx.x < PVW_STAMP_MAX) g_stamp_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // tiled matrix -> packed copy: one thread per (row block, limb, lane) walks its k residue pairs and emits the bit
@@ -3228,6 +3241,13 @@ hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, cons
   sb.row_blocks = (b.nrows + R - 1) / R;
   const u32 blocks = (sa.row_blocks + sb.row_blocks) * L;
   if (blocks == 0) return hipSuccess;
+#if PVW_TUNING
+  if (PVW_ENV_INT("PVW_MAC_VARIANT", 0) == 44) {          // per-workgroup time stamps (tools/mac_timeline.py c3 44)
+    if (ell == 8) mac_rows_packed_kernel<8, true><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+    else mac_rows_packed_kernel<16, true><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+    return hipGetLastError();
+  }
+#endif
   if (ell == 8) mac_rows_packed_kernel<8><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
   else mac_rows_packed_kernel<16><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
   return hipGetLastError();
@@ -3638,7 +3658,8 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
         const u32 span = es->span && es->span < nv - v_lo ? es->span : nv - v_lo, v_hi = v_lo + span;
         const u32 gx = (sec.nrows + 31) / 32, gy = (span + 7) / 8;
         u32 lz = 1;                                          // limb interleave: enough blocks for several rounds on the chip
-        while (lz < L && (size_t)gx * gy * lz < 4096) lz *= 2;
+        const size_t want = (size_t)PVW_ENV_INT("PVW_FINISH_BLOCKS", 4096);   // tuning build: blocks the limb split aims at (1024 .. 16384 measured: 4096)
+        while (lz < L && (size_t)gx * gy * lz < want) lz *= 2;
         if (lz > L) lz = L;
         const dim3 grid(gx, gy, lz);
         switch (ell) {
