@@ -254,7 +254,7 @@ __device__ __forceinline__ u64 pk_get61(const v2u64 (&a)[16], int bit) {
   if (sh > 3) v |= pk_word(a, idx + 1) << (64 - sh);
   return v & PVW_MASK61;
 }
-template <int ELL, bool STAMP = false>
+template <int ELL, bool STAMP = false, bool DEEP = false>
 __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
                                                                const Mod* __restrict__ mods, u32 k, u32 L) {
 #if PVW_TUNING
@@ -291,6 +291,50 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed_kernel(Ma
   acc_zero(a0);
   acc_zero(a1);
   auto ldc = [&](u32 c) -> v2u64 { return __builtin_nontemporal_load(Pp + (size_t)c * 64); };
+  if constexpr (DEEP) {
+    // k = 256 (one period per wave): three windows, the chunks of group g + 2 requested before group g is multiplied --
+    // a group is ~1.2 us of MACs, less than a loaded HBM round trip, so one group of lookahead leaves the wave waiting
+    v2u64 wa[16], wb[16], wc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wa[u] = ldc(u);               // group 0: chunks 0..15
+#pragma unroll
+    for (int u = 1; u < 16; ++u) wb[u] = ldc(15 + u);          // group 1: chunks 16..30 (+ carry 15)
+    __builtin_amdgcn_wave_barrier();
+    constexpr int RN = JC * HALF / 64;
+    {
+      v2u64 rv[RN];
+#pragma unroll
+      for (int x = 0; x < RN; ++x) rv[x] = rp[lane + 64 * x];
+#pragma unroll
+      for (int x = 0; x < RN; ++x) lw[lane + 64 * x] = rv[x];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto macs = [&](const int g, const v2u64 (&cur)[16]) {
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int bit = 32 * g + 122 * jj;
+        const u64 xv = pk_get61(cur, bit), yv = pk_get61(cur, bit + 61);
+        const v2u64 r = lw[(16 * g + jj) * HALF + sp];
+        acc_mac_dev(a0, xv, r.x);
+        acc_mac_dev(a1, yv, r.y);
+      }
+    };
+#pragma unroll
+    for (int u = 1; u < 16; ++u) wc[u] = ldc(30 + u);          // group 2: chunks 31..45 (+ carry 30)
+    __builtin_amdgcn_sched_barrier(0);                         // (the loads are to be ISSUED here, not where hipcc finds room)
+    macs(0, wa);
+    wb[0] = wa[15];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 1; u < 16; ++u) wa[u] = ldc(45 + u);          // group 3: chunks 46..60 (+ carry 45)
+    __builtin_amdgcn_sched_barrier(0);
+    macs(1, wb);
+    wc[0] = wb[15];
+    macs(2, wc);
+    wa[0] = wc[15];
+    macs(3, wa);
+  } else {
   v2u64 xa[16], xb[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) xa[u] = ldc(u);                // group 0 of the first period
@@ -330,6 +374,7 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed_kernel(Ma
     group(1, xb, xa);
     group(2, xa, xb);
     group(3, xb, xa);                                          // leaves the next period's group 0 in xa
+  }
   }
   const Mod m = mods[limb];
   v2u64 part;
@@ -3248,6 +3293,15 @@ hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, cons
     return hipGetLastError();
   }
 #endif
+  // tuning build, PVW_PACKED_DEEP=1 (k = 256): three windows per wave, the chunks of two groups in flight.  Measured equal to the
+  // two-window form (profiles/r02_mac_rows_packed.txt: both land on ~177 or ~185 us at config 3 depending on the launch, not on
+  // the form), so the shipped library keeps the smaller kernel
+  const bool deep = PVW_TUNING && k == 256 && PVW_ENV_INT("PVW_PACKED_DEEP", 0) != 0;
+  if (deep) {
+    if (ell == 8) mac_rows_packed_kernel<8, false, true><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+    else mac_rows_packed_kernel<16, false, true><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+    return hipGetLastError();
+  }
   if (ell == 8) mac_rows_packed_kernel<8><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
   else mac_rows_packed_kernel<16><<<dim3(blocks), dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
   return hipGetLastError();

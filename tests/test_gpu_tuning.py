@@ -55,6 +55,10 @@ def test_mac_rows_packed_and_unpacked_streams_agree(n, k, l, L, monkeypatch):
         monkeypatch.setenv("PVW_MAC_PACKED", packed)
         ct = run()
         assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), packed
+    monkeypatch.setenv("PVW_MAC_PACKED", "1")
+    monkeypatch.setenv("PVW_PACKED_DEEP", "1")              # k = 256: the three-window form of the packed kernel
+    ct = run()
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), "deep"
 
 
 @pytest.mark.parametrize("k,l,L,D", T.DECRYPT_SHAPE_CASES)
