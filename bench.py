@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-probe", action="store_true", help="skip the read-only bandwidth probe (tuning build)")
+    ap.add_argument("--tuning-library", action="store_true",
+                    help="run on libpvw_hip_tuning.so (the measurement build: honours the PVW_* schedule selectors of DESIGN 7a)")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="length of the back-to-back leg reported as `sustained` (0 = skip)")
     args = ap.parse_args()
@@ -96,6 +98,8 @@ def main():
 
     import pvw_rs_amd as P
     from pvw_rs_amd import _ffi
+    if args.tuning_library:
+        _ffi.select("tuning")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,7 +128,7 @@ def main():
         return bench_keygen(args, world, rank, local_rank, dev)
     n_per, k, l, L, desc = CONFIGS[args.config or "c3"]
     n_total = n_per * world
-    moduli = W.bench_moduli(L)
+    moduli = W.config_moduli(args.config or "c3", L)
     from pvw_rs_amd import dist as D
     lo, hi, clo, chi = D.shard_ranges(n_total, k, world, rank)
     params = D.sharded_builder(n_total, k, l, moduli, world, rank, device=local_rank) \
@@ -216,14 +220,15 @@ def main():
     alg_bytes = 8 * L * l * (n_per * k + rows_a * k + nv * (n_per + rows_a + k))
     achieved = alg_bytes / mac_avg_s / 1e9 if mac_avg_s > 0 else 0.0
 
-    # single-dealer launches stream the matrices from their 61-bit packed copy when the geometry qualifies (the rule of
-    # pvw_capi.hip, ensure_packed): the algorithmic bytes stay SURVEY 8d's 8 bytes per residue, the bytes the kernel
-    # actually has to read are reported next to them
-    packed = (Dm == 0 and l <= 16 and k % 256 == 0 and all(q < (1 << 61) for q in moduli)
-              and not (os.environ.get("PVW_HIP_LIBRARY") == "tuning"
-                       and (os.environ.get("PVW_MAC_PACKED") == "0" or os.environ.get("PVW_MAC_VARIANT", "0") != "0")))
-    mac_kernel = "mac_rows_packed_kernel" if packed else "mac_rows_kernel"
-    streamed_bytes = (8 * L * l * ((n_per * k + rows_a * k) * 61 // 64 + nv * (n_per + rows_a + k))) if packed else alg_bytes
+    # single-dealer launches stream the matrices from a bit-packed copy when the geometry qualifies (40 / 48 / 56 / 61 bits
+    # per residue by the widest modulus; the library says which one it used): the algorithmic bytes stay SURVEY 8d's 8
+    # bytes per residue, the bytes the kernel actually has to read are reported next to them
+    width = params.packed_active() if Dm == 0 else 0
+    if args.tuning_library and (os.environ.get("PVW_MAC_PACKED") == "0" or os.environ.get("PVW_MAC_VARIANT", "0") not in ("0", "44")):
+        width = 0
+    packed = width != 0
+    mac_kernel = ("mac_rows_packed61_kernel" if width == 61 else "mac_rows_packedw_kernel") if packed else "mac_rows_kernel"
+    streamed_bytes = (8 * L * l * ((n_per * k + rows_a * k) * width // 64 + nv * (n_per + rows_a + k))) if packed else alg_bytes
     tr = measured_traffic(args.config or "c3", mac_kernel)
     out = {
         "metric": "parties/s for n-party encrypt (pvw::crypto::encrypt); achieved HBM GB/s vs peak",
@@ -239,8 +244,10 @@ def main():
                      "traffic_source": (tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)") if tr else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "streamed_bytes_per_launch": streamed_bytes,
                      "frac_of_streamed_bytes": (streamed_bytes / mac_avg_s / 1e9 / HBM_PEAK_GBS) if mac_avg_s > 0 else 0.0,
-                     "packing": ("matrix residues stored at 61 of 64 bits (mac_rows_packed_kernel): `achieved` / `frac` count the algorithmic "
+                     "packing": (f"matrix residues stored at {width} of 64 bits ({mac_kernel}): `achieved` / `frac` count the algorithmic "
                                  "8 bytes per residue, `frac_of_streamed_bytes` the bytes the kernel reads") if packed else None,
+                     "front": "r-hat and the e1 / e2 + m g addends are made by the leading workgroups of the mac_rows launch (no separate prologue launch)"
+                              if (Dm == 0 and l <= 16 and kt["prologue"][1] == 0) else None,
                      "avg_launch_us": mac_avg_s * 1e6,
                      "launches_timed": mac_launches},
         "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},

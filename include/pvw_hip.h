@@ -28,7 +28,16 @@
  *     `encrypt` (src/crypto/encryption.rs:277-283): device tensors are
  *     read-only after load and every call takes a stream + workspace from a pool.
  *   - *_device calls take device pointers and a hipStream_t (as void*; NULL =
- *     the context's own stream), enqueue asynchronously and do not synchronise.
+ *     the context's own stream) and enqueue asynchronously.  They do not
+ *     synchronise or allocate ONCE pvw_prepare() has run for that stream since
+ *     the matrices last changed.  Without pvw_prepare() the first call on a
+ *     stream allocates that stream's workspace, and the first encrypt after a
+ *     CRS / public-key change builds the derived copies of the matrices it
+ *     streams from (a bit-packed copy for pvw_encrypt_device, an MFMA-tiled copy
+ *     for pvw_encrypt_multi_device): that call allocates up to a second copy of
+ *     the resident matrices and waits for the build.  A call made while its
+ *     stream is being captured into a graph never builds anything: it uses what
+ *     is valid and takes the two-launch form of encrypt.
  *     The context's own stream is created non-blocking: it is NOT ordered against
  *     the legacy default stream, so a caller that prepares or consumes the buffers
  *     on the default stream (stream 0 -- also what a framework's "current stream"
@@ -290,8 +299,29 @@ PVW_API int32_t pvw_sample_gaussian(pvw_ctx* ctx, const uint8_t seed[32], uint32
 PVW_API int32_t pvw_ctx_set_profiling(pvw_ctx* ctx, int32_t on);
 PVW_API int32_t pvw_ctx_kernel_time(pvw_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
 PVW_API int32_t pvw_ctx_reset_profiling(pvw_ctx* ctx);
-/* geometry of the resident tensors (bytes) for roofline bookkeeping */
+/* geometry of the resident tensors (bytes) for roofline bookkeeping: the tiled A-hat / B-hat sections ... */
 PVW_API int32_t pvw_ctx_resident_bytes(const pvw_ctx* ctx, uint64_t* crs_bytes, uint64_t* pk_bytes);
+/* ... and the derived copies held next to them at the moment (0 when not built) */
+PVW_API int32_t pvw_ctx_derived_bytes(const pvw_ctx* ctx, uint64_t* packed_bytes, uint64_t* mfma_tiled_bytes);
+
+/* ---- derived copies as an explicit step (GlobalPublicKey's mutators take &mut self, src/keys/public_key.rs:214-263:
+ * in the reference a key change and an encrypt never overlap, so there is a well-defined moment for this) -------------
+ * pvw_prepare builds, NOW and on `stream` (NULL = the context's own), what later *_device calls on that stream would
+ * otherwise build lazily: the stream's workspace, and for
+ *   PVW_PREPARE_PACKED  the bit-packed copies of A-hat / B-hat that single-dealer encrypt streams (encryption.rs:177-200):
+ *                       40 / 48 / 56 / 61 bits per residue by the widest modulus; l <= 16, k a multiple of 64 (256 at
+ *                       61 bits); skipped -- not an error -- when the geometry does not qualify or memory is short
+ *                       (pvw_ctx_packed_active tells; the tiled matrices are streamed then, and the allocation is
+ *                       retried by later encrypts every so often);
+ *   PVW_PREPARE_MFMA    the MFMA-tiled copies and digit buffers of multi-dealer encrypt (encryption.rs:253-286).
+ * It allocates, waits for the builds, and returns the bytes it allocated for the copies in *bytes_out (may be NULL).
+ * Any later pvw_load_crs* / pvw_load_pk* / pvw_keygen / pvw_*_generate / fill invalidates the copies of the matrix it
+ * touched; call pvw_prepare again (only that matrix's copies are rebuilt; nothing is reallocated). */
+enum { PVW_PREPARE_PACKED = 1, PVW_PREPARE_MFMA = 2 };
+PVW_API int32_t pvw_prepare(pvw_ctx* ctx, uint32_t flags, void* stream, uint64_t* bytes_out);
+/* the stream single-dealer encrypt would use right now: *width_out = bits per residue of the valid packed copies,
+ * 0 = the tiled matrices (copies not built, invalidated, geometry not eligible, or no room) */
+PVW_API int32_t pvw_ctx_packed_active(const pvw_ctx* ctx, uint32_t* width_out);
 PVW_API int32_t pvw_ctx_synchronize(pvw_ctx* ctx);
 
 #ifdef __cplusplus

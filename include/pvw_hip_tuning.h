@@ -1,7 +1,7 @@
 /* pvw_hip_tuning.h -- entry points that exist ONLY in the measurement build libpvw_hip_tuning.so
  * (hipcc -DPVW_TUNING=1, pvw_rs_amd/build.py).  That build also honours the environment switches listed in
- * DESIGN.md section 7a (kernel schedule selectors such as PVW_MAC_VARIANT / PVW_DEC_VARIANT, and the timing
- * ablations PVW_PROLOGUE_DEBUG / PVW_GEMM_DEBUG / PVW_DECODE_TIMING, which produce WRONG results by design).
+ * DESIGN.md section 7a (kernel schedule selectors such as PVW_MAC_VARIANT / PVW_MAC_PACKED / PVW_MAC_FRONT / PVW_DEC_VARIANT,
+ * and the timing aids PVW_DECODE_TIMING / PVW_GEMM_ZERO_OPERANDS, which produce WRONG results by design).
  * The shipped libpvw_hip.so exports none of this and reads no environment variable: the reference samples and
  * computes unconditionally (src/crypto/encryption.rs:135-167), and so must its drop-in.
  * the tools/ scripts, bench.py's read_probe leg and tests/test_gpu_tuning.py load the tuning build; nothing else does. */
@@ -23,12 +23,10 @@ PVW_API int32_t pvw_selftest_read_bandwidth(pvw_ctx* ctx, uint32_t reps, double*
  * contiguous eighth of the matrix instead of every eighth 256-KiB run */
 PVW_API int32_t pvw_tuning_read_probe(pvw_ctx* ctx, uint32_t reps, uint32_t u, uint32_t dbuf, uint32_t lds_bytes,
                                       double* seconds_per_pass, uint64_t* bytes_per_pass);
-/* MEASUREMENT AID (tools/mac_timeline.py): with PVW_MAC_VARIANT=40 (default schedule) or 41 every workgroup of the
+/* MEASUREMENT AID (tools/mac_timeline.py): with PVW_MAC_VARIANT=40 (tiled stream) or 44 (packed stream) every workgroup of the
  * streamed-inner-product kernel records its first and last instruction on the constant 100 MHz counter; this reads
  * them back: stamps [count][2], hw_id [count] (HW_ID register of the workgroup's first wave: XCC, SE, CU). */
 PVW_API int32_t pvw_tuning_read_stamps(pvw_ctx* ctx, uint64_t* stamps, uint32_t* hw_id, uint32_t count);
-/* persistent form (PVW_MAC_VARIANT=42 / 43): per workgroup [b][2] = (tick of its first instruction, XCC_ID << 32 | HW_ID) */
-PVW_API int32_t pvw_tuning_read_wg_stamps(pvw_ctx* ctx, uint64_t* stamps, uint32_t count);
 
 #ifdef __cplusplus
 }

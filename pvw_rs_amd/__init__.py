@@ -5,8 +5,8 @@
 interface over that ABI; `host/pvw.hpp` is the same mirror in C++.
 There is no CPU fallback: device entry points fail loudly without the library / a GPU.
 """
-from ._ffi import (DOM_CRS, DOM_E1, DOM_E2, DOM_EKEY, DOM_GAUSS, DOM_PK, DOM_R, DOM_SK, REPR_NTT,
-                   REPR_POWER)
+from ._ffi import (DOM_CRS, DOM_E1, DOM_E2, DOM_EKEY, DOM_GAUSS, DOM_PK, DOM_R, DOM_SK, PREPARE_MFMA, PREPARE_PACKED,
+                   REPR_NTT, REPR_POWER)
 from .api import (GlobalPublicKey, Party, PvwCiphertext, PvwCrs, PvwError, PvwParameters,
                   PvwParametersBuilder, SecretKey, decode_scalar_pvw, decode_scalar_pvw_host, decrypt_party_shares,
                   decrypt_party_value, device_available, encrypt, encrypt_all_party_shares,

@@ -22,6 +22,7 @@ ERROR_NAMES = {
 REPR_POWER, REPR_NTT = 0, 1
 RND_SEED, RND_EXPLICIT = 0, 1
 DOM_R, DOM_E1, DOM_E2, DOM_SK, DOM_EKEY, DOM_CRS, DOM_GAUSS, DOM_PK = range(8)
+PREPARE_PACKED, PREPARE_MFMA = 1, 2
 
 
 class pvw_params_t(C.Structure):
@@ -94,6 +95,9 @@ _SIGNATURES = {
     "pvw_ctx_kernel_time": [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "pvw_ctx_reset_profiling": [_P],
     "pvw_ctx_resident_bytes": [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "pvw_ctx_derived_bytes": [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "pvw_prepare": [_P, C.c_uint32, _P, C.POINTER(C.c_uint64)],
+    "pvw_ctx_packed_active": [_P, C.POINTER(C.c_uint32)],
     "pvw_ctx_synchronize": [_P],
 }
 
@@ -101,16 +105,16 @@ _SIGNATURES = {
 _TUNING_SIGNATURES = {
     "pvw_selftest_read_bandwidth": [_P, C.c_uint32, _P, _P],
     "pvw_tuning_read_stamps": [_P, _P, _P, C.c_uint32],
-    "pvw_tuning_read_wg_stamps": [_P, _P, C.c_uint32],
     "pvw_tuning_read_probe": [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P],
 }
 
 LIB_TUNING_PATH = os.path.join(HERE, "libpvw_hip_tuning.so")
 _libs = {}
-# which build `lib()` hands out.  "tuning" is for tools/*.sh (PVW_HIP_LIBRARY=tuning in the environment of the
-# PYTHON host -- the shipped .so itself reads no environment variable) and for tests/test_gpu_tuning.py, which
-# switches with `select()`; every PvwParameters remembers the library it was created with.
-_selected = "tuning" if os.environ.get("PVW_HIP_LIBRARY") == "tuning" else "default"
+# which build `lib()` hands out: always the shipped library unless CODE asks for the measurement build with
+# `select("tuning")` (tools/*.py, bench.py --tuning-library, tests/test_gpu_tuning.py).  Nothing in the environment can
+# redirect the package to it -- that build honours switches that change what encrypt computes.  Every PvwParameters
+# remembers the library it was created with.
+_selected = "default"
 
 
 def _load(which: str) -> C.CDLL:

@@ -292,6 +292,24 @@ class PvwParameters:
         self._call("pvw_ctx_resident_bytes", C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def prepare(self, flags: int = _ffi.PREPARE_PACKED | _ffi.PREPARE_MFMA, stream=None) -> int:
+        """pvw_prepare: build the derived copies of the resident matrices (and `stream`'s workspace) now; returns the
+        bytes allocated for them.  After it, *_device calls on that stream neither allocate nor synchronise."""
+        taken = C.c_uint64(0)
+        self._call("pvw_prepare", int(flags), C.c_void_p(stream) if stream else None, C.byref(taken))
+        return int(taken.value)
+
+    def packed_active(self) -> int:
+        """bits per residue of the packed stream single-dealer encrypt would use right now (0 = the tiled matrices)"""
+        w = C.c_uint32(0)
+        self._call("pvw_ctx_packed_active", C.byref(w))
+        return int(w.value)
+
+    def derived_bytes(self) -> Tuple[int, int]:
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._call("pvw_ctx_derived_bytes", C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def synchronize(self) -> None:
         self._call("pvw_ctx_synchronize")
 

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libpvw_hip.so")
 LIB_TUNING = os.path.join(HERE, "libpvw_hip_tuning.so")
-SOURCES = ["pvw_kernels.hip", "pvw_capi.hip"]
+SOURCES = ["pvw_mac.hip", "pvw_poly.hip", "pvw_decrypt.hip", "pvw_decode_kernels.hip", "pvw_gemm.hip", "pvw_capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

@@ -117,7 +117,16 @@ struct Workspace {
   bool own_stream = false;
   u64* rhat = nullptr;       // [L][k][l]  (x4: up to four r-hat / s-hat vectors)
   size_t rhat_bytes = 0;
-  u32* counters = nullptr;   // work-queue words of the persistent mac_rows (zeroed once; the kernel re-arms them)
+  // the front of a fused encrypt launch (pvw_mac.hip): [L] r-hat counters 128 bytes apart, then the addend counter;
+  // they only grow, front_gen counts the launches that advanced them.  front_err: host-visible word a workgroup sets
+  // when it gives up waiting for them.
+  u32* flags = nullptr;
+  u32 front_gen = 0;
+  u32* front_err = nullptr;      // host pointer (hipHostMalloc, mapped)
+  u32* front_err_dev = nullptr;  // the same word as the device sees it
+  // pinned staging pair of the host-buffer encrypt (c1 | c2), allocated on first use
+  u64* pin_out = nullptr;
+  size_t pin_out_bytes = 0;
   u64* dpart = nullptr;      // range sums of a split decrypt_mac [nsplit][dealers][L][l]
   size_t dpart_bytes = 0;
   u64* scalars = nullptr;    // [n]
@@ -187,13 +196,16 @@ struct pvw_ctx {
   u64* xmA = nullptr;
   u64* xmB = nullptr;
   bool xm_valid = false;
-  // packed copies (61 bits per residue) for the single-dealer mac_rows: built lazily by the first encrypt when the
-  // geometry allows it and the memory is there, dropped whenever A or B changes (launch_pack61)
+  // packed copies (pk_width = 40 / 48 / 56 / 61 bits per residue, by the widest modulus) for the single-dealer
+  // mac_rows: built by pvw_prepare, or lazily by the first encrypt after the matrices changed, when the geometry
+  // allows it and the memory is there (launch_pack); a section is rebuilt when ITS matrix changed
   u64* pkA = nullptr;
   u64* pkB = nullptr;
-  u32* pk_flag = nullptr;   // device word: set by pack61_kernel when a matrix word exceeds 61 bits
-  bool pk_valid = false;
-  bool pk_off = false;      // the copy does not fit / the geometry does not qualify: decided once per matrix state
+  u32* pk_flag = nullptr;   // device word: set by pack_kernel when a matrix word exceeds the stream width
+  u32 pk_width = 0;         // 0: the geometry does not qualify (decided at context creation)
+  bool pkA_valid = false, pkB_valid = false;
+  bool pk_wide = false;     // the resident matrices hold unreduced words: no packed stream until they change
+  u32 pk_nomem_calls = 0;   // encrypts since the copies last failed to fit (the allocation is retried now and then)
   bool crs_loaded = false;
   u32 num_keys = 0;
   hipStream_t stream = nullptr;
@@ -337,10 +349,12 @@ static int32_t upload_tables(pvw_ctx* c) {
   };
   c->dt.mods = (const Mod*)put(c->mods.data(), L * sizeof(Mod));
   c->dt.min_q_bits = 64;
+  c->dt.max_q_bits = 0;
   for (u32 i = 0; i < L; ++i) {
     u32 bits = 0;
     for (u64 q = c->mods[i].q; q; q >>= 1) ++bits;
     if (bits < c->dt.min_q_bits) c->dt.min_q_bits = bits;
+    if (bits > c->dt.max_q_bits) c->dt.max_q_bits = bits;
   }
   c->dt.tw = (const u64*)put(c->tw.data(), L * l * 8);
   c->dt.itw = (const u64*)put(c->itw.data(), L * l * 8);
@@ -417,8 +431,11 @@ static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
   PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
   w->rhat_bytes = 4 * k * P * 8;
   PVW_HIP(hipMemset(w->rhat, 0, w->rhat_bytes));          // recycled device memory may hold an earlier owner's data
-  PVW_HIP(hipMalloc((void**)&w->counters, 2048));          // 8 shard counters + 1, one per 128-byte line
-  PVW_HIP(hipMemset(w->counters, 0, 2048));
+  PVW_HIP(hipMalloc((void**)&w->flags, ((size_t)c->L + 1) * 128));
+  PVW_HIP(hipMemset(w->flags, 0, ((size_t)c->L + 1) * 128));
+  PVW_HIP(hipHostMalloc((void**)&w->front_err, 64, hipHostMallocMapped));
+  *w->front_err = 0;
+  PVW_HIP(hipHostGetDevicePointer((void**)&w->front_err_dev, w->front_err, 0));
   return PVW_OK;
 }
 static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
@@ -446,7 +463,9 @@ static void ws_free(Workspace* w) {
   if (w->rhat && w->rhat_bytes) hipMemset(w->rhat, 0, w->rhat_bytes);
   if (w->scratch) hipMemset(w->scratch, 0, w->scratch_bytes);
   hipFree(w->rhat);
-  hipFree(w->counters);
+  hipFree(w->flags);
+  if (w->front_err) hipHostFree(w->front_err);
+  if (w->pin_out) hipHostFree(w->pin_out);
   hipFree(w->dpart);
   hipFree(w->scalars);
   hipFree(w->c1);
@@ -590,6 +609,15 @@ int32_t pvw_ctx_create(const pvw_params_t* p, pvw_ctx** out) {
   }
   build_tables(c);
   build_decode_tables(c);
+  {
+    u32 maxbits = 0;
+    for (u64 q : c->moduli) {
+      u32 bits = 0;
+      for (; q; q >>= 1) ++bits;
+      if (bits > maxbits) maxbits = bits;
+    }
+    c->pk_width = packed_width(maxbits, c->k, c->l);
+  }
   *out = c;
   return PVW_OK;
 }
@@ -697,6 +725,21 @@ int32_t pvw_ctx_resident_bytes(const pvw_ctx* c, uint64_t* crs, uint64_t* pk) {
   if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
   if (crs) *crs = c->tiled_words(c->rowsA()) * 8;
   if (pk) *pk = c->tiled_words(c->rowsB()) * 8;
+  return PVW_OK;
+}
+
+int32_t pvw_ctx_derived_bytes(const pvw_ctx* c, uint64_t* packed, uint64_t* mfma_tiled) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  if (packed) *packed = ((c->pkA ? packed_words(c->rowsA(), c->k, c->L, c->l, c->pk_width) : 0) +
+                         (c->pkB ? packed_words(c->rowsB(), c->k, c->L, c->l, c->pk_width) : 0)) * 8;
+  if (mfma_tiled) *mfma_tiled = ((c->xmA ? xm_words(c->rowsA(), c->k, c->L, c->l) : 0) + (c->xmB ? xm_words(c->rowsB(), c->k, c->L, c->l) : 0)) * 8;
+  return PVW_OK;
+}
+
+int32_t pvw_ctx_packed_active(const pvw_ctx* c, uint32_t* width) {
+  if (!c || !width) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  const bool valid = c->pk_width && !c->pk_wide && (c->pkA_valid || c->rowsA() == 0) && (c->pkB_valid || c->rowsB() == 0);
+  *width = valid ? c->pk_width : 0;
   return PVW_OK;
 }
 
@@ -826,41 +869,80 @@ static int32_t ensure_xm(pvw_ctx* c, hipStream_t s) {
   return PVW_OK;
 }
 
-// packed copies of the resident A-hat / B-hat sections for mac_rows (pvw_kernels.hip, mac_rows_packed_kernel): needs
-// l <= 16, k a multiple of 256, every modulus below 2^61, and room for a second copy of the matrices.  Returns false
-// (and remembers it) when the plain tiled matrices are to be streamed instead.
-static bool ensure_packed(pvw_ctx* c, hipStream_t s) {
+// packed copies of the resident A-hat / B-hat sections for mac_rows (pvw_mac.hip, mac_rows_packed*_kernel): needs
+// l <= 16, k a multiple of 64 (256 at 61 bits), every modulus below 2^61, and room for a second copy of the matrices.
+// Returns the stream width, or 0 when the plain tiled matrices are to be streamed instead.  may_build = false (a
+// stream capture is in progress): only says what is valid already, touches nothing.
+static u32 ensure_packed(pvw_ctx* c, hipStream_t s, bool may_build = true, size_t* bytes_taken = nullptr) {
   // tuning build: A/B runs against the unpacked stream, and an explicit schedule of the unpacked kernel is honoured
-  if (PVW_ENV_INT("PVW_MAC_PACKED", 1) == 0 || (PVW_ENV_INT("PVW_MAC_VARIANT", 0) != 0 && PVW_ENV_INT("PVW_MAC_VARIANT", 0) != 44)) return false;
+  if (PVW_ENV_INT("PVW_MAC_PACKED", 1) == 0 || (PVW_ENV_INT("PVW_MAC_VARIANT", 0) != 0 && PVW_ENV_INT("PVW_MAC_VARIANT", 0) != 44)) return 0;
+  if (c->pk_width == 0) return 0;
   std::lock_guard<std::mutex> g(c->init_mu);
-  if (c->pk_valid) return true;
-  if (c->pk_off) return false;
-  c->pk_off = true;                                     // until proven otherwise
-  if (c->l > 16 || c->k % 256 != 0) return false;
-  for (u64 q : c->moduli)
-    if (q >> 61) return false;
   const u32 rA = c->rowsA(), rB = c->rowsB();
-  const size_t wa = packed_words(rA, c->k, c->L, c->l), wb = packed_words(rB, c->k, c->L, c->l);
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-  const size_t have = (c->pkA ? 0 : wa * 8) + (c->pkB ? 0 : wb * 8);
-  if (free_b < have + ((size_t)4 << 30)) return false;  // leave room for the callers' own buffers
-  if (!c->pkA && wa && hipMalloc((void**)&c->pkA, wa * 8) != hipSuccess) return false;
-  if (!c->pkB && wb && hipMalloc((void**)&c->pkB, wb * 8) != hipSuccess) return false;
-  if (!c->pk_flag && hipMalloc((void**)&c->pk_flag, sizeof(u32)) != hipSuccess) return false;
-  if (hipMemsetAsync(c->pk_flag, 0, sizeof(u32), s) != hipSuccess) return false;
+  if (c->pk_wide) return 0;
+  if ((c->pkA_valid || rA == 0) && (c->pkB_valid || rB == 0)) return c->pk_width;
+  if (!may_build) return 0;
+  const size_t wa = packed_words(rA, c->k, c->L, c->l, c->pk_width), wb = packed_words(rB, c->k, c->L, c->l, c->pk_width);
+  const size_t need = (c->pkA || !wa ? 0 : wa * 8) + (c->pkB || !wb ? 0 : wb * 8);
+  if (need) {
+    // memory was short the last time: look again every 64th encrypt, not on every call
+    if (c->pk_nomem_calls && (c->pk_nomem_calls++ & 63) != 0) return 0;
+    size_t free_b = 0, total_b = 0;
+    bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= need + ((size_t)4 << 30);   // leave room for the callers' own buffers
+    if (ok && !c->pkA && wa) ok = hipMalloc((void**)&c->pkA, wa * 8) == hipSuccess;
+    if (ok && !c->pkB && wb) ok = hipMalloc((void**)&c->pkB, wb * 8) == hipSuccess;
+    if (!ok) {
+      // nothing half-built stays behind, and a failed hipMalloc does not poison the next launch's hipGetLastError()
+      if (!c->pkA_valid) { hipFree(c->pkA); c->pkA = nullptr; }
+      if (!c->pkB_valid) { hipFree(c->pkB); c->pkB = nullptr; }
+      (void)hipGetLastError();
+      if (c->pk_nomem_calls == 0) c->pk_nomem_calls = 1;
+      return 0;
+    }
+    c->pk_nomem_calls = 0;
+    if (bytes_taken) *bytes_taken += need;
+  }
+  if (!c->pk_flag && hipMalloc((void**)&c->pk_flag, sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipMemsetAsync(c->pk_flag, 0, sizeof(u32), s) != hipSuccess) return 0;
   {
-    ProfScope ps(c, "pack61", s);
-    if (launch_pack61(c->dA, c->pkA, rA, c->k, c->L, c->l, c->pk_flag, s) != hipSuccess) return false;
-    if (launch_pack61(c->dB, c->pkB, rB, c->k, c->L, c->l, c->pk_flag, s) != hipSuccess) return false;
+    ProfScope ps(c, "pack", s);
+    if (!c->pkA_valid && launch_pack(c->dA, c->pkA, rA, c->k, c->L, c->l, c->pk_width, c->pk_flag, s) != hipSuccess) return 0;
+    if (!c->pkB_valid && launch_pack(c->dB, c->pkB, rB, c->k, c->L, c->l, c->pk_width, c->pk_flag, s) != hipSuccess) return 0;
   }
   u32 wide = 1;
-  if (hipMemcpyAsync(&wide, c->pk_flag, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return false;
-  if (hipStreamSynchronize(s) != hipSuccess) return false;
-  if (wide) return false;                               // residues were loaded unreduced: stream the tiled matrices as they are
-  c->pk_valid = true;
-  c->pk_off = false;
-  return true;
+  if (hipMemcpyAsync(&wide, c->pk_flag, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
+  if (hipStreamSynchronize(s) != hipSuccess) return 0;
+  if (wide) {                                             // residues were loaded unreduced: stream the tiled matrices as they are
+    c->pk_wide = true;
+    return 0;
+  }
+  c->pkA_valid = c->pkB_valid = true;
+  return c->pk_width;
+}
+
+// The derived copies and the calling stream's workspace, built NOW: after this, pvw_encrypt_device /
+// pvw_encrypt_multi_device on `stream` neither allocate nor synchronise until a matrix changes again (GlobalPublicKey's
+// mutators take &mut self, public_key.rs:214-263: a change and a use never overlap).
+int32_t pvw_prepare(pvw_ctx* c, uint32_t flags, void* stream, uint64_t* bytes_out) {
+  if (!c) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL context");
+  if (flags & ~(uint32_t)(PVW_PREPARE_PACKED | PVW_PREPARE_MFMA)) return fail(PVW_ERR_INVALID_PARAMETERS, "unknown prepare flag");
+  PVW_TRY(ensure_device(c));
+  if (!c->crs_loaded) return fail(PVW_ERR_CRS, "CRS not loaded");
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  Workspace* w;
+  PVW_TRY(ws_for_stream(c, s, &w));
+  size_t taken = 0;
+  if (flags & PVW_PREPARE_PACKED) (void)ensure_packed(c, s, true, &taken);       // 0 = does not qualify / no room: pvw_ctx_packed_active tells
+  if (flags & PVW_PREPARE_MFMA) {
+    const bool had_a = c->xmA != nullptr, had_b = c->xmB != nullptr;
+    PVW_TRY(ws_gemm_buffers(c, w));
+    PVW_TRY(ensure_xm(c, s));
+    if (!had_a && c->xmA) taken += xm_words(c->rowsA(), c->k, c->L, c->l) * 8;
+    if (!had_b && c->xmB) taken += xm_words(c->rowsB(), c->k, c->L, c->l) * 8;
+  }
+  PVW_HIP(hipStreamSynchronize(s));
+  if (bytes_out) *bytes_out = taken;
+  return PVW_OK;
 }
 
 static int32_t check_repr(uint32_t repr) {
@@ -872,7 +954,7 @@ int32_t pvw_load_crs(pvw_ctx* c, const uint64_t* a, uint32_t repr) {
   if (!c || !a) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(check_repr(repr));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
+  c->xm_valid = false; c->pkA_valid = false; c->pk_wide = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   PVW_TRY(load_rows_host(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, a, repr));
   c->crs_loaded = true;
@@ -882,7 +964,7 @@ int32_t pvw_load_crs_device(pvw_ctx* c, const uint64_t* d_a, uint32_t repr, void
   if (!c || !d_a) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(check_repr(repr));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
+  c->xm_valid = false; c->pkA_valid = false; c->pk_wide = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   PVW_TRY(load_rows_device(c, c->dA, c->c1_lo, c->c1_hi, 0, c->k, d_a, repr, s));
@@ -892,7 +974,7 @@ int32_t pvw_load_crs_device(pvw_ctx* c, const uint64_t* d_a, uint32_t repr, void
 int32_t pvw_crs_generate(pvw_ctx* c, const uint8_t seed[32]) {
   if (!c || !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
+  c->xm_valid = false; c->pkA_valid = false; c->pk_wide = false;
   PVW_TRY(ensure_matrix(c, &c->dA, c->rowsA()));
   {
     ProfScope ps(c, "fill_uniform", c->stream);
@@ -1026,7 +1108,7 @@ int32_t pvw_load_pk(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t* b, uin
   PVW_TRY(check_repr(repr));
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
+  c->xm_valid = false; c->pkB_valid = false; c->pk_wide = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   PVW_TRY(load_rows_host(c, c->dB, c->party_lo, c->party_hi, lo, hi, b, repr));
   if (hi > c->num_keys) c->num_keys = hi;                                          // public_key.rs:245-247
@@ -1037,7 +1119,7 @@ int32_t pvw_load_pk_device(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t*
   PVW_TRY(check_repr(repr));
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
+  c->xm_valid = false; c->pkB_valid = false; c->pk_wide = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   PVW_TRY(load_rows_device(c, c->dB, c->party_lo, c->party_hi, lo, hi, d_b, repr, s));
@@ -1047,7 +1129,7 @@ int32_t pvw_load_pk_device(pvw_ctx* c, uint32_t lo, uint32_t hi, const uint64_t*
 int32_t pvw_pk_fill_uniform(pvw_ctx* c, const uint8_t seed[32]) {
   if (!c || !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
+  c->xm_valid = false; c->pkB_valid = false; c->pk_wide = false;
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));
   {
     ProfScope ps(c, "fill_uniform", c->stream);
@@ -1301,26 +1383,63 @@ static int32_t fill_encrypt_jobs(pvw_ctx* c, PrologueBatch& pb, u32 slot, u32 /*
   return PVW_OK;
 }
 
+// a workgroup of an earlier fused launch on this workspace gave up waiting for its producers (pvw_mac.hip, front):
+// report it once, bring the counters back to a known state
+static int32_t front_check(Workspace* w, hipStream_t s) {
+  if (!w->front_err || *w->front_err == 0) return PVW_OK;
+  hipStreamSynchronize(s);
+  *w->front_err = 0;
+  w->front_gen = 0;                        // the next fused launch clears the counters before it uses them
+  return fail(PVW_ERR_INTERNAL, "an encrypt launch timed out waiting for its r-hat / addend producers; its results are invalid");
+}
+
 // all pointers are device pointers; explicit r/e1/e2 are GLOBAL arrays ([k][l], [k][l], [n][l])
 static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, const pvw_randomness_t* rnd,
                                u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
   const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
-  const bool packed = ensure_packed(c, s);                  // first call after a matrix change: builds the packed copies
+  PVW_TRY(front_check(w, s));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  (void)hipGetLastError();
+  // first call after a matrix change (and no pvw_prepare since): builds the packed copies -- allocates and synchronises
+  const u32 width = ensure_packed(c, s, !capturing);
   PrologueBatch pb{};
   PVW_TRY(fill_encrypt_jobs(c, pb, 0, 0, rnd, d_scalars, w->rhat, d_c1, d_c2));
-  pb.njobs = (u32)PVW_ENV_INT("PVW_PROLOGUE_JOBS", 3);     // tuning build, timing experiment (results wrong): 1 = r only
-  {
+  // l <= 16: r-hat and the addends are made by the leading workgroups of the MAC launch itself (pvw_mac.hip, front).
+  // The launch's targets are host-side generation counts, so a launch that is being captured into a graph (and would be
+  // replayed with the same targets) takes the two-launch form, as does l >= 32.  Tuning build: PVW_MAC_FRONT=0.
+  const bool fused = l <= 16 && !capturing && PVW_ENV_INT("PVW_MAC_FRONT", 1) != 0;
+  MacFront front{};
+  if (fused) {
+    front.r = pb.job[0]; front.e1 = pb.job[1]; front.e2 = pb.job[2];
+    front.key = pb.key[0];
+    front.nb = (k + 255) / 256;
+    front.ne = (rA + rB + 63) / 64;
+    if (w->front_gen == 0) PVW_HIP(hipMemsetAsync(w->flags, 0, ((size_t)L + 1) * 128, s));
+    ++w->front_gen;
+    front.target_r = w->front_gen * front.nb;
+    front.target_e = w->front_gen * front.ne;
+    front.flag_r = w->flags;
+    front.flag_e = w->flags + (size_t)L * 32;
+    front.err = w->front_err_dev;
+  } else {
+    pb.njobs = 3;
     ProfScope ps(c, "prologue", s);
     PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
   }
   {
     ProfScope ps(c, "mac_rows", s);
-    if (packed) {
+    hipError_t e;
+    if (width) {
       MacSection a{c->pkA, d_c1, d_c1, rA, 0}, b{c->pkB, d_c2, d_c2, rB, 0};
-      PVW_HIP(launch_mac_rows_packed(a, b, w->rhat, c->dt, k, L, l, s));             // the same sums over the 61-bit packed copy
+      e = launch_mac_rows_packed(a, b, w->rhat, c->dt, k, L, l, width, s, fused ? &front : nullptr);   // the same sums over the packed copy
     } else {
       MacSection a{c->dA, d_c1, d_c1, rA, 0}, b{c->dB, d_c2, d_c2, rB, 0};
-      PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s, w->counters));       // crs.rs:188-201, encryption.rs:177-200
+      e = launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s, fused ? &front : nullptr);                 // crs.rs:188-201, encryption.rs:177-200
+    }
+    if (e != hipSuccess) {
+      if (fused) --w->front_gen;                       // nothing advanced the counters
+      return fail(PVW_ERR_INTERNAL, std::string("HIP error: ") + hipGetErrorString(e) + " at mac_rows launch");
     }
   }
   if (out_repr == PVW_REPR_POWER) {
@@ -1666,13 +1785,6 @@ int32_t pvw_tuning_read_stamps(pvw_ctx* c, uint64_t* stamps, uint32_t* hw_id, ui
   PVW_TRY(ensure_device(c));
   PVW_HIP(hipDeviceSynchronize());
   PVW_HIP(read_stamps(stamps, hw_id, count));
-  return PVW_OK;
-}
-int32_t pvw_tuning_read_wg_stamps(pvw_ctx* c, uint64_t* stamps, uint32_t count) {
-  if (!c || !stamps) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
-  PVW_TRY(ensure_device(c));
-  PVW_HIP(hipDeviceSynchronize());
-  PVW_HIP(read_wg_stamps(stamps, count));
   return PVW_OK;
 }
 #endif  // PVW_TUNING
@@ -2058,7 +2170,7 @@ int32_t pvw_keygen(pvw_ctx* c, uint32_t lo, uint32_t hi, const int64_t* sk, cons
   if (!ek && !seed) return fail(PVW_ERR_INVALID_PARAMETERS, "either explicit key errors or a seed is required");
   PVW_TRY(check_party_range(c, lo, hi));
   PVW_TRY(ensure_device(c));
-  c->xm_valid = false; c->pk_valid = false; c->pk_off = false;
+  c->xm_valid = false; c->pkB_valid = false; c->pk_wide = false;
   if (!c->crs_loaded) return fail(PVW_ERR_CRS, "CRS not loaded");
   if (c->rowsA() != c->k) return fail(PVW_ERR_KEY_GENERATION, "key generation needs the full CRS on this context");
   PVW_TRY(ensure_matrix(c, &c->dB, c->rowsB()));

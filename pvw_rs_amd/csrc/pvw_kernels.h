@@ -1,4 +1,4 @@
-// pvw_kernels.h -- launch interface of the gfx950 kernels (pvw_kernels.hip).
+// pvw_kernels.h -- launch interface of the gfx950 kernels (pvw_mac / pvw_poly / pvw_decrypt / pvw_decode_kernels / pvw_gemm .hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -7,9 +7,8 @@
 #include "pvw_decode.h"
 
 // PVW_TUNING selects the MEASUREMENT build (libpvw_hip_tuning.so, pvw_rs_amd/build.py): only there are the
-// timing / ablation switches (PVW_PROLOGUE_DEBUG, PVW_GEMM_DEBUG, PVW_DECODE_TIMING, -DPVW_GEMM_ABLATE), the
-// schedule selectors (PVW_MAC_VARIANT, PVW_DEC_VARIANT, PVW_DECODE_VARIANT, ...), the measured-and-rejected kernel
-// forms they select and the read-bandwidth probe compiled in.  The shipped library (PVW_TUNING 0) holds the
+// timing switches (PVW_DECODE_TIMING, PVW_GEMM_ZERO_OPERANDS), the schedule selectors (PVW_MAC_VARIANT, PVW_MAC_PACKED,
+// PVW_DEC_C, PVW_DECODE_VARIANT, ...) and the read-bandwidth probe compiled in.  The shipped library (PVW_TUNING 0) holds the
 // shape-selected schedules only and reads NO environment variable: nothing outside the arguments of a call can
 // change what it computes (the reference samples unconditionally, src/crypto/encryption.rs:135-167).
 #ifndef PVW_TUNING
@@ -18,10 +17,8 @@
 #if PVW_TUNING
 #include <cstdlib>
 #define PVW_ENV_INT(name, dflt) ([]() -> long { const char* e_ = getenv(name); return e_ ? atol(e_) : (long)(dflt); }())
-#define PVW_PDBG(b, bit) (((b).debug & (bit)) != 0)
 #else
 #define PVW_ENV_INT(name, dflt) ((long)(dflt))
-#define PVW_PDBG(b, bit) false
 #endif
 
 namespace pvw {
@@ -43,6 +40,7 @@ struct DevTables {
   const u64* ghatp;
   const u64* gpowp;
   u32 min_q_bits;    // bit length of the smallest modulus (kernels with a fast path for wide moduli test it)
+  u32 max_q_bits;    // ... of the widest one (packed stream width; byte count of the digit GEMM)
 };
 
 enum { SAMPLE_CBD = 0, SAMPLE_UNIFORM = 1 };
@@ -66,11 +64,6 @@ struct MacSection {
   u32 nrows;
   u32 row_blocks;
 };
-// c1 (section a: A-hat rows) and c2 (section b: B-hat rows) in a single launch.  `counters`: two zeroed u32 words
-// owned by the calling stream's workspace (work queue of the persistent form; the kernel re-arms them itself);
-// NULL selects the one-workgroup-per-item form.
-hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat,
-                           const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s, u32* counters = nullptr);
 // group != 0: polynomial p goes to out + (p / group) * stride_group + (p % group) * stride_poly
 hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t stride_poly,
                        size_t stride_limb, u32 count, bool do_ntt, const DevTables& t, u32 L,
@@ -112,21 +105,39 @@ struct PrologueBatch {   // sizeof must stay below the 4 KiB kernel-argument lim
   u32 njobs;
   u32 reps;    // 0 is read as 1
   u32 total;   // filled in by the launcher (polynomials per replica)
-  u32 debug;   // filled in by the launcher (timing experiments)
   u32 key_window, key_rep;   // filled in by the launcher: replica r reads keys [r * key_rep, r * key_rep + key_window)
 };
 hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s);
 
-// the same over the PACKED copy of the sections (61 bits per residue; MacSection::M = the packed copy): l <= 16,
-// k a multiple of 256, every modulus below 2^61.  launch_pack61 builds that copy from the tiled matrix:
-// packed_words(rows) u64 per section.
+// The small-polynomial work of ONE encrypt as leading workgroups of the mac_rows launch itself (pvw_mac.hip, "front"):
+// r -> r-hat (encryption.rs:135-154), NTT(e1) -> the c1 rows (:161-167), NTT(e2) + m g-hat -> the c2 rows (:195-196);
+// the MAC adds onto the rows.  nb == 0: no front (r-hat and the addends were made by an earlier launch).
+struct MacFront {
+  PrologueJob r, e1, e2;     // out / strides / sampler of each family (key_idx and the rep_* fields are not used)
+  ChaChaKey key;
+  u32 nb;                    // r-hat producer blocks per limb: ceil(k / 256); blocks [0, L nb)
+  u32 ne;                    // addend producer blocks, 64 polynomials each; blocks [L nb, L nb + ne)
+  u32 target_r, target_e;    // counter values that say "this launch's producers are done" (the counters only grow)
+  u32* flag_r;               // [L] counters, 32 words (128 bytes) apart
+  u32* flag_e;               // one counter
+  u32* err;                  // host-visible word, set when a workgroup gave up waiting
+};
+// c1 (section a: A-hat rows) and c2 (section b: B-hat rows) in a single launch; front != NULL (l <= 16): with the
+// producers of r-hat and of the addends as its first workgroups
+hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L, u32 ell,
+                           hipStream_t s, const MacFront* front = nullptr);
+// the same over the PACKED copy of the sections (`width` bits per residue; MacSection::M = the packed copy).
+// packed_width: the stream width for a modulus chain whose widest modulus has max_q_bits bits -- 40 / 48 / 56 (k a
+// multiple of 64) or 61 (k a multiple of 256), l <= 16 -- or 0 when the geometry does not qualify.  launch_pack
+// builds the copy from the tiled matrix: packed_words(rows, ..., width) u64 per section.
+u32 packed_width(u32 max_q_bits, u32 k, u32 ell);
 hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L,
-                                  u32 ell, hipStream_t s);
-// *wide_flag (device word, zeroed by the caller) is set when a matrix word does not fit 61 bits: the copy is then unusable
-hipError_t launch_pack61(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, u32* wide_flag, hipStream_t s);
-inline size_t packed_words(u32 rows, u32 k, u32 L, u32 ell) {
+                                  u32 ell, u32 width, hipStream_t s, const MacFront* front = nullptr);
+// *wide_flag (device word, zeroed by the caller) is set when a matrix word does not fit `width` bits: the copy is then unusable
+hipError_t launch_pack(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, u32 width, u32* wide_flag, hipStream_t s);
+inline size_t packed_words(u32 rows, u32 k, u32 L, u32 ell, u32 width) {
   const u32 R = 128 / ell;
-  return (size_t)((rows + R - 1) / R) * L * (k / 64 * 61) * 128;
+  return (size_t)((rows + R - 1) / R) * L * (k / 64 * width) * 128;
 }
 // NV (<= 4) vectors sharing one pass over the tiled matrix (mac_rows_multi)
 struct MultiVec {
@@ -152,7 +163,7 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
 hipError_t launch_decrypt_finish(const u64* partial, u32 nsplit, const u64* c2col, u64* noisy, const DevTables& t, u32 L, u32 ell,
                                  size_t dealers, hipStream_t s);
 
-// ---- digit GEMM on the matrix cores (see pvw_kernels.hip) ----
+// ---- digit GEMM on the matrix cores (see pvw_gemm.hip) ----
 #ifndef PVW_GEMM_RPW
 #define PVW_GEMM_RPW 1                                   // row tiles (of 32 rows) per wave
 #endif
@@ -216,7 +227,7 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
 #if PVW_TUNING
 // time stamps (100 MHz ticks, [2b] start / [2b+1] end) and HW_ID words of the workgroups of the last stamped mac_rows launch
 hipError_t read_stamps(u64* out, u32* hw, u32 count);
-hipError_t read_wg_stamps(u64* out, u32 count);   // persistent form: (kernel entry tick, XCC_ID << 32 | HW_ID) per workgroup
+hipError_t init_probe_attributes();
 hipError_t launch_read_probe(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, hipStream_t s);
 hipError_t launch_read_probe2(const u64* M, size_t total_tiles, u32 tiles_per_wave, u64* sink, u32 U, bool dbuf, u32 lds_bytes,
                               hipStream_t s, u32 xmap = 0);

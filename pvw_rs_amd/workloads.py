@@ -43,6 +43,15 @@ def _is_prime(n: int) -> bool:
     return True
 
 
+# the reference's own "128-bit" chain: 4 x 56 bits (examples/pvw_valid_dec.rs:40-45)
+REFERENCE_128_MODULI = [0x800000022A0001, 0x800000021A0001, 0x80000002120001, 0x80000001F60001]
+
+
+def config_moduli(name: str, limbs: int) -> List[int]:
+    """modulus chain of a bench configuration: SURVEY 8d's 61-bit chain unless the configuration names its own"""
+    return list(REFERENCE_128_MODULI[:limbs]) if name == "ref128x" else bench_moduli(limbs)
+
+
 def bench_moduli(count: int) -> List[int]:
     """First `count` primes of the chain (the table above; continued by search beyond it)."""
     out = list(_CHAIN_2_61_STEP_64[:count])
@@ -62,6 +71,7 @@ ENCRYPT_CONFIGS: Dict[str, Tuple[int, int, int, int, str]] = {
     "c3x4": (16384, 256, 8, 17, "sizing experiment: config 3 geometry with n=16384 parties on one GPU"),
     "c4full": (16384, 512, 16, 34, "BASELINE configs[3] in full on ONE GPU: n=16384, k=512, l=16, 2074-bit q (B-hat 36.5 GB)"),
     "c4shard": (2048, 512, 16, 34, "BASELINE configs[3] per-GPU shard: n=16384/8, k=512, l=16, 2074-bit q"),
+    "ref128x": (4096, 1024, 8, 4, "the reference's own 128-bit set (examples/pvw_valid_dec.rs:40-52: k=1024, l=8, 4 x 56-bit q) at n=4096 parties"),
 }
 DECRYPT_CONFIGS: Dict[str, Tuple[int, int, int, int, str]] = {
     "c5shard": (1024, 512, 16, 34, "BASELINE configs[4] per-GPU shard: D=8192/8 dealer ciphertexts, k=512, l=16, 2074-bit q"),

@@ -148,5 +148,8 @@ extern "C" {
     pub fn pvw_ctx_kernel_time(ctx: *mut PvwCtx, name: *const c_char, total_ms: *mut f64, launches: *mut u64) -> i32;
     pub fn pvw_ctx_reset_profiling(ctx: *mut PvwCtx) -> i32;
     pub fn pvw_ctx_resident_bytes(ctx: *const PvwCtx, crs_bytes: *mut u64, pk_bytes: *mut u64) -> i32;
+    pub fn pvw_ctx_derived_bytes(ctx: *const PvwCtx, packed_bytes: *mut u64, mfma_tiled_bytes: *mut u64) -> i32;
+    pub fn pvw_prepare(ctx: *mut PvwCtx, flags: u32, stream: *mut c_void, bytes_out: *mut u64) -> i32;
+    pub fn pvw_ctx_packed_active(ctx: *const PvwCtx, width_out: *mut u32) -> i32;
     pub fn pvw_ctx_synchronize(ctx: *mut PvwCtx) -> i32;
 }

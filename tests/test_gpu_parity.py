@@ -337,11 +337,21 @@ MAC_SCHEDULE_CASES = [(40, 256, 8, 3), (21, 128, 16, 2), (9, 64, 8, 2), (5, 24, 
 # geometries that qualify for the 61-bit packed stream (l <= 16, k a multiple of 256): one and two periods per wave,
 # ragged row blocks, l = 8 and 16, three periods (k = 768)
 MAC_PACKED_CASES = [(40, 256, 8, 3), (19, 512, 16, 2), (133, 512, 8, 2), (9, 768, 8, 2), (70, 256, 16, 3)]
+# narrower modulus chains stream at 40 / 48 / 56 bits per residue (k a multiple of 64): the reference's own sets --
+# 36/37-bit (tests/crypto.rs:52) and 56-bit (examples/pvw_valid_dec.rs:40-45) -- and a 48-bit chain; one to five groups
+# of 16 j per wave (k = 64 .. 320), ragged row blocks, l = 8 and 16
+MAC_PACKED_WIDTH_CASES = [
+    (40, 256, 8, TEST_MODULI, 40), (9, 64, 8, TEST_MODULI, 40), (21, 128, 16, TEST_MODULI, 40), (33, 320, 8, TEST_MODULI, 40),
+    (40, 256, 8, primes_1mod(64, 3, top=1 << 48), 48), (17, 192, 16, primes_1mod(64, 2, top=1 << 48), 48),
+    (40, 256, 8, EXAMPLE_MODULI, 56), (11, 64, 16, EXAMPLE_MODULI, 56), (5, 1024, 8, EXAMPLE_MODULI, 56),
+    (23, 576, 8, EXAMPLE_MODULI[:2], 56),
+]
 
 
-def mac_rows_case(n, k, l, L):
+def mac_rows_case(n, k, l, L, moduli=None):
     """(encrypt closure, oracle c1, oracle c2) for one geometry: c1, c2 of encryption.rs:158,177-200"""
-    moduli = M.bench_moduli(L)
+    moduli = moduli or M.bench_moduli(L)
+    L = len(moduli)
     p = build_params(n, k, l, moduli)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
     gpk.fill_uniform(SEED)
@@ -353,7 +363,9 @@ def mac_rows_case(n, k, l, L):
     e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
     e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
     c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), np.array(scalars, dtype=np.uint64), r, e1, e2)
-    return (lambda: P.encrypt(scalars, gpk, SEED)), c1o, c2o
+    run = lambda: P.encrypt(scalars, gpk, SEED)   # noqa: E731
+    run.params = p
+    return run, c1o, c2o
 
 
 @pytest.mark.parametrize("n,k,l,L", MAC_SCHEDULE_CASES)
@@ -371,6 +383,48 @@ def test_mac_rows_over_the_packed_matrix_agrees_with_c_oracle(n, k, l, L):
     run, c1o, c2o = mac_rows_case(n, k, l, L)
     for _ in range(2):
         ct = run()
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+        assert run.params.packed_active() == 61               # the packed kernel is what ran, not a silent fall-back
+
+
+@pytest.mark.parametrize("n,k,l,moduli,width", MAC_PACKED_WIDTH_CASES)
+def test_mac_rows_streams_at_the_modulus_width(n, k, l, moduli, width):
+    # mac_rows_packedw_kernel: residues of a 36/37-, 48- or 56-bit chain stored at 40 / 48 / 56 bits (pack_kernel)
+    run, c1o, c2o = mac_rows_case(n, k, l, None, moduli)
+    for _ in range(2):
+        ct = run()
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+        assert run.params.packed_active() == width
+
+
+def test_prepare_builds_the_derived_copies_up_front():
+    # pvw_prepare: allocation, build and synchronisation happen there; a key change invalidates the copies of the
+    # matrix it touched and a second prepare rebuilds them in place (no new allocation)
+    n, k, l = 40, 256, 8
+    moduli = M.bench_moduli(2)
+    p = build_params(n, k, l, moduli)
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+    gpk.fill_uniform(SEED)
+    assert p.packed_active() == 0 and p.derived_bytes() == (0, 0)
+    taken = p.prepare(P.PREPARE_PACKED | P.PREPARE_MFMA)
+    packed_b, mfma_b = p.derived_bytes()
+    crs_b, pk_b = p.resident_bytes()
+    assert p.packed_active() == 61 and taken == packed_b + mfma_b
+    assert packed_b == (crs_b + pk_b) * 61 // 64 and mfma_b >= crs_b + pk_b
+    assert p.prepare(P.PREPARE_PACKED | P.PREPARE_MFMA) == 0            # nothing left to build
+    orc = O.Oracle(moduli, l)
+    a_hat = orc.fill_uniform(SEED, M.DOM_CRS, 0, k * k).reshape(k, k, 2, l)
+    scalars = np.arange(1, n + 1, dtype=np.uint64)
+    r = O.sample_cbd(SEED, M.DOM_R, 0, k, l, 0.5)
+    e1 = O.sample_uniform(SEED, M.DOM_E1, 0, k, l, 100)
+    e2 = O.sample_uniform(SEED, M.DOM_E2, 0, n, l, 200)
+    for seed in (SEED, bytes([0x31]) * 32):
+        gpk.fill_uniform(seed)                                           # B-hat changed: its packed copy is stale
+        assert p.packed_active() == 0
+        assert p.prepare(P.PREPARE_PACKED) == 0 and p.packed_active() == 61 and p.derived_bytes()[0] == packed_b
+        b_hat = orc.fill_uniform(seed, M.DOM_PK, 0, n * k).reshape(n, k, 2, l)
+        c1o, c2o = orc.encrypt(a_hat, b_hat, p.gadget_polynomial(P.REPR_NTT), scalars, r, e1, e2)
+        ct = P.encrypt(scalars, gpk, SEED)
         assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
 
 
@@ -391,7 +445,7 @@ def test_packed_matrix_follows_key_changes_and_wide_moduli_fall_back():
         b_hat = orc.fill_uniform(seed, M.DOM_PK, 0, n * k).reshape(n, k, 2, l)
         c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, scalars, r, e1, e2)
         ct = P.encrypt(scalars, gpk, SEED)
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o) and p.packed_active() == 61
     # residues loaded UNREDUCED (r + q needs 62 bits): the copy would truncate them, so it must not be used
     b_hat = orc.fill_uniform(SEED, M.DOM_PK, 0, n * k).reshape(n, k, 2, l)
     unreduced = b_hat.copy()
@@ -402,6 +456,10 @@ def test_packed_matrix_follows_key_changes_and_wide_moduli_fall_back():
     c1o, c2o = orc.encrypt(a_hat, b_hat, g_hat, scalars, r, e1, e2)
     ct = P.encrypt(scalars, gpk, SEED)
     assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+    assert p.packed_active() == 0                                      # the tiled matrices were streamed
+    gpk.load_rows(0, b_hat, P.REPR_NTT)                                # reduced again: the packed stream comes back
+    ct = P.encrypt(scalars, gpk, SEED)
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o) and p.packed_active() == 61
     # a modulus of 62 bits does not fit the 61-bit stream: the unpacked kernel must serve it
     wide = primes_1mod(64, 2, top=(1 << 62) - 64)        # top must be a multiple of the step
     assert all(q >> 61 for q in wide)
@@ -413,7 +471,7 @@ def test_packed_matrix_follows_key_changes_and_wide_moduli_fall_back():
     b2 = orc2.fill_uniform(SEED, M.DOM_PK, 0, n * k).reshape(n, k, 2, l)
     c1o, c2o = orc2.encrypt(a2, b2, p2.gadget_polynomial(P.REPR_NTT), scalars, r, e1, e2)
     ct = P.encrypt(scalars, gpk2, SEED)
-    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
+    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o) and p2.packed_active() == 0
 
 
 DECRYPT_SHAPE_CASES = [

@@ -29,36 +29,44 @@ def test_tuning_build_is_selected():
     assert p._lib.pvw_build_is_tuning() == 1 and _ffi._load("default").pvw_build_is_tuning() == 0
 
 
-@pytest.mark.parametrize("n,k,l,L", T.MAC_SCHEDULE_CASES + [
-    (20, 512, 8, 2), (10, 256, 16, 2),      # two r-hat chunks per item (small: the persistent variants fall back)
-    (14000, 256, 8, 2),                      # 1782 items: the persistent kernel proper, one chunk per item
-    (3000, 256, 16, 4),                      # 1628 items, l = 16, two chunks per item
-    (1700, 512, 16, 4),                      # 1108 items, four chunks per item (variant 30; 31 falls back)
-])
+@pytest.mark.parametrize("n,k,l,L", T.MAC_SCHEDULE_CASES + [(20, 512, 8, 2), (10, 256, 16, 2), (3000, 256, 16, 4)])
 def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
-    # every streaming schedule of mac_rows (PVW_MAC_VARIANT) computes the same c1, c2 (encryption.rs:158,177-200)
-    # 0-19 schedules of the one-workgroup-per-item kernel, 20 / 23 the same with a register cap, 24 / 25 two waves per item, 30 / 31 the
-    # persistent kernel (21 / 22 are timing ablations with wrong results by design and are not walked)
+    # the schedules of the tiled-stream mac_rows that are left (PVW_MAC_VARIANT: 0 by shape -- which streams the packed copy
+    # where it can --, 17 not interleaved, 40 interleaved + time stamps), each with the front inside the launch and as
+    # a separate prologue launch (PVW_MAC_FRONT): the same c1, c2 (encryption.rs:158,177-200)
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for variant in list(range(0, 21)) + [23, 24, 25, 30, 31]:
-        monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
-        ct = run()
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
+    for front in ("1", "0"):
+        monkeypatch.setenv("PVW_MAC_FRONT", front)
+        for variant in (0, 17, 40):
+            monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
+            ct = run()
+            assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (front, variant)
 
 
 @pytest.mark.parametrize("n,k,l,L", T.MAC_PACKED_CASES)
 def test_mac_rows_packed_and_unpacked_streams_agree(n, k, l, L, monkeypatch):
     # PVW_MAC_PACKED=0: the geometries the shipped library streams from the 61-bit packed copy, served by the
-    # unpacked mac_rows_kernel instead -- same ciphertexts, both equal to the oracle's
+    # unpacked mac_rows_kernel instead; PVW_MAC_FRONT=0: r-hat and the addends from a separate prologue launch; 44:
+    # the stamped packed kernel -- same ciphertexts, all equal to the oracle's
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for packed in ("1", "0"):
+    for packed, front, variant, width in (("1", "1", "0", 61), ("0", "1", "0", 0), ("1", "0", "0", 61), ("0", "0", "0", 0), ("1", "1", "44", 61)):
         monkeypatch.setenv("PVW_MAC_PACKED", packed)
+        monkeypatch.setenv("PVW_MAC_FRONT", front)
+        monkeypatch.setenv("PVW_MAC_VARIANT", variant)
         ct = run()
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), packed
-    monkeypatch.setenv("PVW_MAC_PACKED", "1")
-    monkeypatch.setenv("PVW_PACKED_DEEP", "1")              # k = 256: the three-window form of the packed kernel
-    ct = run()
-    assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), "deep"
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (packed, front, variant)
+        if packed == "1":
+            assert run.params.packed_active() == width
+
+
+@pytest.mark.parametrize("n,k,l,moduli,width", T.MAC_PACKED_WIDTH_CASES[:7])
+def test_mac_rows_width_streams_with_a_separate_prologue(n, k, l, moduli, width, monkeypatch):
+    run, c1o, c2o = T.mac_rows_case(n, k, l, None, moduli)
+    for front, variant in (("0", "0"), ("1", "44")):
+        monkeypatch.setenv("PVW_MAC_FRONT", front)
+        monkeypatch.setenv("PVW_MAC_VARIANT", variant)
+        ct = run()
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o) and run.params.packed_active() == width
 
 
 @pytest.mark.parametrize("k,l,L,D", T.DECRYPT_SHAPE_CASES)
@@ -67,7 +75,7 @@ def test_decrypt_mac_launch_shapes_agree_with_c_oracle(k, l, L, D, monkeypatch):
     # polynomials: the shape-selected default, the dealer-grouped form and the full-width form, each with 1, 2, 3
     # j-replicas
     run, want = T.decrypt_mac_case(k, l, L, D)
-    for variant, c in [(0, 0), (10, 0), (10, 2), (10, 3), (11, 0), (60, 0), (60, 1), (60, 2), (61, 3), (62, 0), (64, 0)]:
+    for variant, c in [(0, 0), (10, 0), (10, 2), (10, 3), (60, 0), (60, 1), (60, 2), (60, 3)]:
         monkeypatch.setenv("PVW_DEC_VARIANT", str(variant))
         monkeypatch.setenv("PVW_DEC_C", str(c))
         assert np.array_equal(run(), want), (variant, c)
@@ -82,9 +90,8 @@ def test_multi_dealer_encrypt_on_the_integer_valu(D, monkeypatch):
 
 @pytest.mark.parametrize("l,moduli", [(8, TEST_MODULI), (8, M.bench_moduli(17)), (16, M.bench_moduli(34)), (64, primes_1mod(128, 5))])
 def test_device_decode_forms_match_model(l, moduli, monkeypatch):
-    # decode_scalar_pvw_rns (decryption.rs:10-58): lifted chain with 4 / 2 / 8 waves per ciphertext, one wave per
-    # ciphertext with an RNS round trip per step, one thread per ciphertext
-    T.device_decode_case(l, moduli, lambda v: monkeypatch.setenv("PVW_DECODE_VARIANT", str(v)), (0, 3, 4, 2, 1))
+    # decode_scalar_pvw_rns (decryption.rs:10-58): the lifted chain (four waves per ciphertext) and one thread per ciphertext
+    T.device_decode_case(l, moduli, lambda v: monkeypatch.setenv("PVW_DECODE_VARIANT", str(v)), (0, 1))
 
 
 @pytest.mark.parametrize("D", [5, 70])
@@ -113,38 +120,33 @@ def test_read_bandwidth_probe_runs():
     assert 500.0 < nbytes.value / sec.value / 1e9 < 8000.0
 
 
-def _encrypt_once(lib_name):
-    prev = _ffi.select(lib_name)
-    try:
-        p = T.build_params(40, 16, 8, M.bench_moduli(3))
-        gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
-        gpk.fill_uniform(SEED)
-    finally:
-        _ffi.select(prev)
-    ct = P.encrypt([(i * 1000 + 1) % (1 << 32) for i in range(40)], gpk, SEED)
-    return ct.c1.copy(), ct.c2.copy()
+def test_switches_exist_only_in_the_tuning_build(monkeypatch):
+    # PVW_MAC_PACKED=0 makes the TUNING build stream the tiled matrices; the shipped library has neither the lookup nor
+    # the branch, so no variable can change what it runs (the reference samples and computes unconditionally,
+    # encryption.rs:135-167) -- and the ciphertexts are the same either way
+    def once(lib_name):
+        prev = _ffi.select(lib_name)
+        try:
+            p = T.build_params(40, 256, 8, M.bench_moduli(3))
+            gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
+            gpk.fill_uniform(SEED)
+        finally:
+            _ffi.select(prev)
+        ct = P.encrypt([(i * 1000 + 1) % (1 << 32) for i in range(40)], gpk, SEED)
+        return ct.c1.copy(), ct.c2.copy(), p.packed_active()
+    want = once("default")
+    assert want[2] == 61 and once("tuning")[2] == 61
+    for name, val in (("PVW_MAC_PACKED", "0"), ("PVW_MAC_FRONT", "0"), ("PVW_DECODE_TIMING", "1"), ("PVW_GEMM_ZERO_OPERANDS", "1"), ("PVW_MAC_VARIANT", "17")):
+        monkeypatch.setenv(name, val)
+    got = once("default")
+    assert all(np.array_equal(a, b) for a, b in zip(got[:2], want[:2])) and got[2] == 61, "the shipped library reacted to a tuning variable"
+    got_t = once("tuning")
+    assert all(np.array_equal(a, b) for a, b in zip(got_t[:2], want[:2])) and got_t[2] == 0
 
 
-def test_prologue_debug_switch_exists_only_in_the_tuning_build(monkeypatch):
-    # PVW_PROLOGUE_DEBUG=1 makes the TUNING build skip sampling (a timing ablation: ciphertexts without
-    # randomness); the shipped library has neither the lookup nor the branch, so the variable cannot touch it
-    # (the reference samples unconditionally, encryption.rs:135-167)
-    want = _encrypt_once("default")
-    assert all(np.array_equal(a, b) for a, b in zip(_encrypt_once("tuning"), want))
-    monkeypatch.setenv("PVW_PROLOGUE_DEBUG", "1")
-    monkeypatch.setenv("PVW_GEMM_DEBUG", "3")
-    monkeypatch.setenv("PVW_DECODE_TIMING", "1")
-    monkeypatch.setenv("PVW_MAC_VARIANT", "7")
-    got = _encrypt_once("default")
-    assert all(np.array_equal(a, b) for a, b in zip(got, want)), "the shipped library reacted to a debug variable"
-    got_t = _encrypt_once("tuning")
-    assert not np.array_equal(got_t[1], want[1]), "the tuning build should have skipped sampling"
-
-
-@pytest.mark.parametrize("form", [1, 2])
-def test_digit_gemm_wide_forms_agree(form, monkeypatch):
-    # PVW_GEMM_WIDE: 1 = 8 waves in step, 2 = 4 waves / two workgroups per CU (3, ping-pong, is what ships and what
-    # tests/test_gpu_parity.py runs): same ciphertexts from every form, k = 256 and k = 512
-    monkeypatch.setenv("PVW_GEMM_WIDE", str(form))
+def test_digit_gemm_round1_form_agrees(monkeypatch):
+    # PVW_GEMM_WIDE=0: more than 16 vectors through gemm_digits_kernel (128 rows x 16 vectors per workgroup) instead of the
+    # wide ping-pong form that ships and that tests/test_gpu_parity.py runs: same ciphertexts, k = 256 and k = 512
+    monkeypatch.setenv("PVW_GEMM_WIDE", "0")
     T.test_digit_gemm_multi_dealer_equals_separate_encrypts(100, 256, 8, 3, 40)
     T.test_digit_gemm_multi_dealer_equals_separate_encrypts(40, 512, 16, 2, 17)

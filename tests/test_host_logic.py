@@ -34,7 +34,7 @@ def test_tuning_library_is_a_superset_and_the_shipped_one_has_no_switches():
     import subprocess
     tuning_h = open(os.path.join(ROOT, "include", "pvw_hip_tuning.h")).read()
     extra = re.findall(r"^PVW_API int32_t (pvw_\w+)\(", tuning_h, flags=re.M)
-    assert extra == ["pvw_selftest_read_bandwidth", "pvw_tuning_read_probe", "pvw_tuning_read_stamps", "pvw_tuning_read_wg_stamps"] and set(extra) == set(_ffi._TUNING_SIGNATURES)
+    assert extra == ["pvw_selftest_read_bandwidth", "pvw_tuning_read_probe", "pvw_tuning_read_stamps"] and set(extra) == set(_ffi._TUNING_SIGNATURES)
     dflt, tun = _ffi._load("default"), _ffi.tuning_lib()
     assert dflt.pvw_build_is_tuning() == 0 and tun.pvw_build_is_tuning() == 1
     for name in extra:
@@ -45,7 +45,7 @@ def test_tuning_library_is_a_superset_and_the_shipped_one_has_no_switches():
         return subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout
     def undefined(path):
         return subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
-    switches = ("PVW_PROLOGUE_DEBUG", "PVW_GEMM_DEBUG", "PVW_DECODE_TIMING", "PVW_MAC_VARIANT", "PVW_DEC_VARIANT",
+    switches = ("PVW_GEMM_ZERO_OPERANDS", "PVW_DECODE_TIMING", "PVW_MAC_VARIANT", "PVW_MAC_PACKED", "PVW_MAC_FRONT", "PVW_DEC_VARIANT",
                 "PVW_GEMM_MIN_DEALERS", "PVW_KEYGEN_SWAP")
     s_def, s_tun = strings(_ffi.LIB_PATH), strings(_ffi.LIB_TUNING_PATH)
     for name in switches:

@@ -1,11 +1,10 @@
 #!/bin/bash
 # the schedule selectors exist in the measurement build only (include/pvw_hip_tuning.h)
-export PVW_HIP_LIBRARY=tuning
 # sweep of decrypt_mac launch shapes: PVW_DEC_VARIANT x PVW_DEC_C on two decrypt workloads
 out=gpurun_out/dec_sweep.log; : > $out
 run() {
   echo "cfg $1 variant $2 c $3" >> $out
-  PVW_DEC_VARIANT=$2 PVW_DEC_C=$3 timeout -k 10 200 python bench.py --path decrypt --config $1 --steps 30 --warmup 5 2>/dev/null | python -c "
+  PVW_DEC_VARIANT=$2 PVW_DEC_C=$3 timeout -k 10 200 python bench.py --tuning-library --path decrypt --config $1 --steps 30 --warmup 5 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

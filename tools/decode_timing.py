@@ -4,9 +4,11 @@ import os, sys
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path[:0] = [ROOT]
-os.environ["PVW_HIP_LIBRARY"] = "tuning"      # PVW_DECODE_TIMING exists in the measurement build only
 from pvw_rs_amd import workloads as M
 import pvw_rs_amd as P
+from pvw_rs_amd import _ffi
+
+_ffi.select("tuning")      # PVW_DECODE_TIMING exists in the measurement build only
 
 L, l, count = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 moduli = M.bench_moduli(L)

@@ -12,11 +12,12 @@ import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path[:0] = [ROOT]
-os.environ["PVW_HIP_LIBRARY"] = "tuning"
 import torch  # noqa: E402,F401  (device memory only)
 
 import pvw_rs_amd as P  # noqa: E402
 from pvw_rs_amd import _ffi, workloads as W  # noqa: E402
+
+_ffi.select("tuning")   # the measurement build: schedule selectors, stamps, probes
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 variant = sys.argv[2] if len(sys.argv) > 2 else "40"

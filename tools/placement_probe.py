@@ -8,12 +8,13 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path[:0] = [ROOT]
-os.environ["PVW_HIP_LIBRARY"] = "tuning"
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import torch  # noqa: E402
 
 import pvw_rs_amd as P  # noqa: E402
 from pvw_rs_amd import _ffi, workloads as W  # noqa: E402
+
+_ffi.select("tuning")   # the measurement build: schedule selectors, stamps, probes
 
 n, k, l, L, _ = W.ENCRYPT_CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
 dev = torch.device("cuda", 0)

@@ -11,7 +11,7 @@ import csv, glob, collections
 f = glob.glob("gpurun_out/pmc_mac/p1/**/*_counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if "mac_rows_kernel" in r["Kernel_Name"]:
+    if "mac_rows" in r["Kernel_Name"] and "multi" not in r["Kernel_Name"]:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
     print(k, "avg per launch %.4g" % (sum(v) / len(v)), "launches", len(v))

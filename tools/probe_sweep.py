@@ -10,8 +10,10 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path[:0] = [ROOT]
-os.environ["PVW_HIP_LIBRARY"] = "tuning"
 import pvw_rs_amd as P  # noqa: E402
+from pvw_rs_amd import _ffi  # noqa: E402
+
+_ffi.select("tuning")   # the probes live in the measurement build
 from pvw_rs_amd import workloads as W  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
