@@ -35,6 +35,7 @@ from pvw_rs_amd import workloads as W          # noqa: E402  (pure Python: geome
 CONFIGS = W.ENCRYPT_CONFIGS
 DECRYPT_CONFIGS = W.DECRYPT_CONFIGS
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DIST_ON = False                # a process group exists (N > 1, or PVW_BENCH_FORCE_DIST=1 at N = 1)
 SEED_A, SEED_B, SEED_ENC = W.SEED_A, W.SEED_B, W.SEED_ENC
 
 
@@ -111,9 +112,21 @@ def main():
     if not torch.cuda.is_available() or not P.device_available():
         print("bench.py needs a gfx950 GPU: the PVW hot path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    if world > 1:
+    # PVW_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, CRS broadcast, barrier, max-reduce of the time,
+    # all-gather of the decrypt) with world_size 1 -- RCCL exercised on a one-GPU box
+    global DIST_ON
+    DIST_ON = world > 1 or os.environ.get("PVW_BENCH_FORCE_DIST") == "1"
+    if DIST_ON:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            sock.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL ("nccl") over xGMI in production; PVW_BENCH_BACKEND=gloo only to rehearse the N>1 code path
         # on a box with fewer GPUs than ranks (see PVW_BENCH_SAME_DEVICE below)
         dist.init_process_group(backend=os.environ.get("PVW_BENCH_BACKEND", "nccl"))
@@ -137,7 +150,7 @@ def main():
     lib = _ffi.lib()
 
     # ---- residency: A-hat (generated on rank 0, broadcast ONCE over RCCL/xGMI), B-hat shard ----
-    if world > 1:
+    if DIST_ON:
         a_host = None
         if rank == 0:
             p0 = (P.PvwParametersBuilder().set_parties(n_total).set_dimension(k).set_l(l).set_moduli(moduli)
@@ -180,7 +193,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST_ON:
             import torch.distributed as dist
             dist.barrier()
 
@@ -193,7 +206,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if DIST_ON:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,7 +251,7 @@ def main():
         "config": {"workload": desc, "parties_per_gpu": n_per, "parties_total": n_total, "k": k, "l": l,
                    "rns_limbs": L, "q_bits": int(params.q_total().bit_length()), "randomness": "seed (ChaCha8), on device", "dealers_per_step": max(Dm, 1),
                    "sharding": f"party-sharded x{world}, A-hat broadcast once, no data-path collective",
-                   "world_size_observed": world, "backend": (os.environ.get("PVW_BENCH_BACKEND", "nccl") if world > 1 else None)},
+                   "world_size_observed": world, "backend": (os.environ.get("PVW_BENCH_BACKEND", "nccl") if DIST_ON else None)},
         "roofline": {"bound": "hbm", "kernel": mac_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                      "traffic_source": (tr[1] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)") if tr else None,
@@ -342,6 +355,38 @@ def main():
                                    "note": "pvw_encrypt with pageable host buffers, synchronous, PCIe-inclusive (c1+c2 = "
                                            f"{(k + n_total) * L * l * 8 / 1e6:.1f} MB D2H per call); median of 20 calls",
                                    "bit_exact_vs_device_path": bool(np.array_equal(c2h.view(np.int64), c2.cpu().numpy()))}
+        # ... and with the output buffers in pinned, device-visible host memory (pvw_host_alloc): the MAC stores the ciphertexts
+        # straight into them while it runs -- no copy after the kernel
+        try:
+            ptrs = []
+            def pinned(shape):
+                nbytes = int(np.prod(shape)) * 8
+                pp = C.c_void_p()
+                if lib.pvw_host_alloc(nbytes, C.byref(pp)) != 0:
+                    raise RuntimeError(_ffi.last_error())
+                ptrs.append(pp)
+                return np.ctypeslib.as_array((C.c_uint64 * (nbytes // 8)).from_address(pp.value)).reshape(shape)
+            c1p, c2p = pinned((k, L, l)), pinned((n_total, L, l))
+            t_pin = []
+            for it in range(23):
+                t_h2 = time.perf_counter()
+                rc = lib.pvw_encrypt(h, sc_host.ctypes.data_as(C.c_void_p), n_total, C.byref(rnd),
+                                     c1p.ctypes.data_as(C.c_void_p), c2p.ctypes.data_as(C.c_void_p), P.REPR_NTT)
+                if rc != 0:
+                    raise RuntimeError(_ffi.last_error())
+                if it >= 3:
+                    t_pin.append(time.perf_counter() - t_h2)
+            t_p = sorted(t_pin)[len(t_pin) // 2]
+            out["host_buffer_path"]["pinned_output"] = {
+                "ms_per_encrypt": t_p * 1e3, "ms_min": min(t_pin) * 1e3, "parties_per_s": n_total / t_p,
+                "note": "pvw_encrypt with c1 / c2 in pvw_host_alloc memory: the kernel writes them over PCIe as its workgroups finish",
+                "bit_exact_vs_device_path": bool(np.array_equal(c2p.view(np.int64), c2.cpu().numpy()) and
+                                                 np.array_equal(c1p.view(np.int64), c1.cpu().numpy()))}
+            del c1p, c2p
+            for pp in ptrs:
+                lib.pvw_host_free(pp)
+        except Exception as e:
+            out["host_buffer_path"]["pinned_output"] = {"error": str(e)[:200]}
         # the ONLY place bench.py touches oracle/: the checker timed as the CPU baseline
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pvw_model as M
@@ -373,7 +418,7 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if DIST_ON:
         import torch.distributed as dist
         dist.destroy_process_group()
 
@@ -453,7 +498,7 @@ def bench_decrypt(args, world, rank, local_rank, dev):
 
     vals_dev = torch.zeros(D, dtype=torch.int64, device=dev)
     # config 5's one exchange step: every rank ends up with all D x world decoded shares (8 bytes each)
-    gathered = torch.zeros(D * world, dtype=torch.int64, device=dev) if world > 1 else None
+    gathered = torch.zeros(D * world, dtype=torch.int64, device=dev) if DIST_ON else None
 
     def step():
         # inner products, INTT and gadget decode on the device: only D x u64 would leave the GPU
@@ -462,13 +507,13 @@ def bench_decrypt(args, world, rank, local_rank, dev):
                                           C.c_void_p(noisy.data_ptr()), C.c_void_p(vals_dev.data_ptr()), stream)
         if rc != 0:
             raise RuntimeError(_ffi.last_error())
-        if world > 1:
+        if DIST_ON:
             import torch.distributed as dist
             dist.all_gather(list(gathered.chunk(world)), vals_dev)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST_ON:
             import torch.distributed as dist
             dist.barrier()
 
@@ -481,7 +526,7 @@ def bench_decrypt(args, world, rank, local_rank, dev):
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if DIST_ON:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -513,7 +558,8 @@ def bench_decrypt(args, world, rank, local_rank, dev):
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": desc, "dealers_per_gpu": D, "k": k, "l": l, "rns_limbs": L,
                    "q_bits": int(params.q_total().bit_length()),
-                   "sharding": f"dealer-sharded x{world}" + (", all-gather of D x u64 decoded shares per step" if world > 1 else "")},
+                   "sharding": f"dealer-sharded x{world}" + (", all-gather of D x u64 decoded shares per step" if DIST_ON else ""),
+                   "world_size_observed": world, "backend": (os.environ.get("PVW_BENCH_BACKEND", "nccl") if DIST_ON else None)},
         "roofline": {"bound": "hbm", "kernel": "decrypt_mac_fw_kernel" if L * l // 2 >= 128 else "decrypt_mac_grouped_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
@@ -525,7 +571,7 @@ def bench_decrypt(args, world, rank, local_rank, dev):
     }
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if DIST_ON:
         import torch.distributed as dist
         dist.destroy_process_group()
 

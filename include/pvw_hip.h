@@ -299,6 +299,14 @@ PVW_API int32_t pvw_sample_gaussian(pvw_ctx* ctx, const uint8_t seed[32], uint32
 PVW_API int32_t pvw_ctx_set_profiling(pvw_ctx* ctx, int32_t on);
 PVW_API int32_t pvw_ctx_kernel_time(pvw_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
 PVW_API int32_t pvw_ctx_reset_profiling(pvw_ctx* ctx);
+/* Host memory the device can write directly (pinned + mapped).  pvw_encrypt recognises output buffers that live in
+ * such memory -- from here, or pinned / registered by the caller (hipHostMalloc, hipHostRegister) -- and, for
+ * PVW_REPR_NTT output, has the kernel store c1 / c2 straight into them while it runs: the ciphertexts (4.7 MB at
+ * n = 4096, k = 256, 1037-bit q) cross PCIe under the kernel instead of in a copy after it.  Pageable buffers work as
+ * before.  (encryption.rs:105 returns host objects; a Rust host allocates the Vec it converts from with this.) */
+PVW_API int32_t pvw_host_alloc(size_t bytes, void** out);
+PVW_API int32_t pvw_host_free(void* p);
+
 /* geometry of the resident tensors (bytes) for roofline bookkeeping: the tiled A-hat / B-hat sections ... */
 PVW_API int32_t pvw_ctx_resident_bytes(const pvw_ctx* ctx, uint64_t* crs_bytes, uint64_t* pk_bytes);
 /* ... and the derived copies held next to them at the moment (0 when not built) */

@@ -94,6 +94,8 @@ _SIGNATURES = {
     "pvw_ctx_set_profiling": [_P, C.c_int32],
     "pvw_ctx_kernel_time": [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "pvw_ctx_reset_profiling": [_P],
+    "pvw_host_alloc": [C.c_size_t, C.POINTER(_P)],
+    "pvw_host_free": [_P],
     "pvw_ctx_resident_bytes": [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "pvw_ctx_derived_bytes": [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "pvw_prepare": [_P, C.c_uint32, _P, C.POINTER(C.c_uint64)],

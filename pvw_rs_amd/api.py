@@ -404,7 +404,10 @@ class SecretKey:
         return SecretKey(params, a)
 
     def coefficients(self) -> np.ndarray:
-        return self.secret_coeffs
+        """A COPY of the coefficients (secret_key.rs:280-292 hands out a slice tied to the key's lifetime; numpy cannot
+        express that, and a view would silently turn to zeros when the key is dropped).  The caller owns the copy and
+        wipes it.  `secret_coeffs` is the key's own storage: cleared by zeroize() / on drop."""
+        return self.secret_coeffs.copy()
 
     def zeroize(self) -> None:
         """Zeroize / ZeroizeOnDrop (secret_key.rs:20-30): overwrite the coefficients in place (the device side
@@ -479,8 +482,10 @@ class GlobalPublicKey:
             while j < len(parties) and parties[j].index == parties[j - 1].index + 1:
                 j += 1
             sk = np.stack([pt.secret_key.secret_coeffs for pt in parties[i:j]])
-            self._keygen(parties[i].index, parties[i].index + (j - i), sk, None, seed)
-            sk.fill(0)
+            try:
+                self._keygen(parties[i].index, parties[i].index + (j - i), sk, None, seed)
+            finally:
+                sk.fill(0)                                 # the stacked copy does not outlive the call, whatever happened
             i = j
 
     def generate_with_errors(self, party_lo: int, sk: np.ndarray, ek: np.ndarray) -> None:

@@ -117,16 +117,14 @@ struct Workspace {
   bool own_stream = false;
   u64* rhat = nullptr;       // [L][k][l]  (x4: up to four r-hat / s-hat vectors)
   size_t rhat_bytes = 0;
-  // the front of a fused encrypt launch (pvw_mac.hip): [L] r-hat counters 128 bytes apart, then the addend counter;
+  // the front of a fused encrypt launch (pvw_mac.hip): block counters and "ready" words (PVW_FRONT_* in pvw_kernels.h);
   // they only grow, front_gen counts the launches that advanced them.  front_err: host-visible word a workgroup sets
   // when it gives up waiting for them.
   u32* flags = nullptr;
   u32 front_gen = 0;
+  long front_mode = -1;          // which families the counters have been counting (a change restarts them)
   u32* front_err = nullptr;      // host pointer (hipHostMalloc, mapped)
   u32* front_err_dev = nullptr;  // the same word as the device sees it
-  // pinned staging pair of the host-buffer encrypt (c1 | c2), allocated on first use
-  u64* pin_out = nullptr;
-  size_t pin_out_bytes = 0;
   u64* dpart = nullptr;      // range sums of a split decrypt_mac [nsplit][dealers][L][l]
   size_t dpart_bytes = 0;
   u64* scalars = nullptr;    // [n]
@@ -431,8 +429,8 @@ static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
   PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
   w->rhat_bytes = 4 * k * P * 8;
   PVW_HIP(hipMemset(w->rhat, 0, w->rhat_bytes));          // recycled device memory may hold an earlier owner's data
-  PVW_HIP(hipMalloc((void**)&w->flags, ((size_t)c->L + 1) * 128));
-  PVW_HIP(hipMemset(w->flags, 0, ((size_t)c->L + 1) * 128));
+  PVW_HIP(hipMalloc((void**)&w->flags, (size_t)PVW_FRONT_WORDS * 4));
+  PVW_HIP(hipMemset(w->flags, 0, (size_t)PVW_FRONT_WORDS * 4));
   PVW_HIP(hipHostMalloc((void**)&w->front_err, 64, hipHostMallocMapped));
   *w->front_err = 0;
   PVW_HIP(hipHostGetDevicePointer((void**)&w->front_err_dev, w->front_err, 0));
@@ -465,7 +463,6 @@ static void ws_free(Workspace* w) {
   hipFree(w->rhat);
   hipFree(w->flags);
   if (w->front_err) hipHostFree(w->front_err);
-  if (w->pin_out) hipHostFree(w->pin_out);
   hipFree(w->dpart);
   hipFree(w->scalars);
   hipFree(w->c1);
@@ -1330,6 +1327,32 @@ int32_t pvw_encode_scalar(const pvw_ctx* cc, int64_t scalar, uint64_t* poly_out,
   return small_to_poly_impl(c, zero.data(), &s, 1, poly_out, repr);
 }
 
+// the device's address for [p, p + bytes) if p is host memory the GPU can write (hipHostMalloc / hipHostRegister), else NULL
+static void* device_alias(void* p, size_t bytes) {
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // pageable memory: not an error
+  if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+  hipPointerAttribute_t last{};
+  if (hipPointerGetAttributes(&last, (char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (last.type != hipMemoryTypeHost || (char*)last.devicePointer - (char*)at.devicePointer != (ptrdiff_t)(bytes - 1)) return nullptr;
+  return at.devicePointer;
+}
+
+// host memory the device can read and write directly (pinned, mapped): output buffers placed here receive pvw_encrypt's
+// ciphertexts without a copy
+int32_t pvw_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(PVW_ERR_INTERNAL, "no HIP device available");
+  PVW_HIP(hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocPortable));
+  return PVW_OK;
+}
+int32_t pvw_host_free(void* p) {
+  if (p) PVW_HIP(hipHostFree(p));
+  return PVW_OK;
+}
+
 // ------------------------------------------------------------------------ encrypt
 static int32_t encrypt_checks(pvw_ctx* c, size_t num_scalars, const pvw_randomness_t* rnd, uint32_t out_repr) {
   PVW_TRY(check_repr(out_repr));
@@ -1394,9 +1417,14 @@ static int32_t front_check(Workspace* w, hipStream_t s) {
 }
 
 // all pointers are device pointers; explicit r/e1/e2 are GLOBAL arrays ([k][l], [k][l], [n][l])
+// out_c1 / out_c2 != NULL: the MAC stores its results there (device-visible HOST memory of a caller whose buffers are
+// pinned) while the addends stay in d_c1 / d_c2; NTT-domain output only
 static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, const pvw_randomness_t* rnd,
-                               u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s) {
+                               u64* d_c1, u64* d_c2, uint32_t out_repr, hipStream_t s, u64* out_c1 = nullptr, u64* out_c2 = nullptr) {
   const u32 k = c->k, l = c->l, L = c->L, rA = c->rowsA(), rB = c->rowsB();
+  if (!out_c1) out_c1 = d_c1;
+  if (!out_c2) out_c2 = d_c2;
+  if (out_repr == PVW_REPR_POWER && (out_c1 != d_c1 || out_c2 != d_c2)) return fail(PVW_ERR_INTERNAL, "direct output is NTT-domain only");
   PVW_TRY(front_check(w, s));
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
@@ -1405,23 +1433,34 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
   const u32 width = ensure_packed(c, s, !capturing);
   PrologueBatch pb{};
   PVW_TRY(fill_encrypt_jobs(c, pb, 0, 0, rnd, d_scalars, w->rhat, d_c1, d_c2));
-  // l <= 16: r-hat and the addends are made by the leading workgroups of the MAC launch itself (pvw_mac.hip, front).
-  // The launch's targets are host-side generation counts, so a launch that is being captured into a graph (and would be
-  // replayed with the same targets) takes the two-launch form, as does l >= 32.  Tuning build: PVW_MAC_FRONT=0.
-  const bool fused = l <= 16 && !capturing && PVW_ENV_INT("PVW_MAC_FRONT", 1) != 0;
+  // l <= 16: r-hat is a small launch of its own and the addends are made by the leading workgroups of the MAC launch
+  // (pvw_mac.hip, front).  The launch's generation number is host-side state, so a launch that is being captured into a
+  // graph (and would be replayed with the same number) takes the two-launch form (one prologue launch for r-hat and the
+  // addends, then the MAC), as does l >= 32.  Tuning build: PVW_MAC_FRONT = 0 that form everywhere, 2 r-hat producers
+  // inside the MAC launch as well.
+  const long front_mode = l <= 16 && !capturing ? PVW_ENV_INT("PVW_MAC_FRONT", 1) : 0;
+  const bool fused = front_mode != 0;
   MacFront front{};
   if (fused) {
     front.r = pb.job[0]; front.e1 = pb.job[1]; front.e2 = pb.job[2];
     front.key = pb.key[0];
-    front.nb = (k + 255) / 256;
+    front.nb = front_mode == 2 ? (k + 255) / 256 : 0;
     front.ne = (rA + rB + 63) / 64;
-    if (w->front_gen == 0) PVW_HIP(hipMemsetAsync(w->flags, 0, ((size_t)L + 1) * 128, s));
+    if (w->front_mode != front_mode) { w->front_mode = front_mode; w->front_gen = 0; }
+    if (w->front_gen == 0) PVW_HIP(hipMemsetAsync(w->flags, 0, (size_t)PVW_FRONT_WORDS * 4, s));
     ++w->front_gen;
-    front.target_r = w->front_gen * front.nb;
+    front.gen = w->front_gen;
+    front.target_r = w->front_gen * (L * front.nb);
     front.target_e = w->front_gen * front.ne;
-    front.flag_r = w->flags;
-    front.flag_e = w->flags + (size_t)L * 32;
+    front.cnt_r = w->flags + PVW_FRONT_CNT_R;
+    front.cnt_e = w->flags + PVW_FRONT_CNT_E;
+    front.ready_r = w->flags + PVW_FRONT_READY_R;
+    front.ready_e = w->flags + PVW_FRONT_READY_E;
     front.err = w->front_err_dev;
+    if (front.nb == 0) {
+      ProfScope ps(c, "prologue", s);
+      PVW_HIP(launch_front_r(front, c->dt, k, L, l, s));
+    }
   } else {
     pb.njobs = 3;
     ProfScope ps(c, "prologue", s);
@@ -1431,10 +1470,10 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
     ProfScope ps(c, "mac_rows", s);
     hipError_t e;
     if (width) {
-      MacSection a{c->pkA, d_c1, d_c1, rA, 0}, b{c->pkB, d_c2, d_c2, rB, 0};
+      MacSection a{c->pkA, d_c1, out_c1, rA, 0}, b{c->pkB, d_c2, out_c2, rB, 0};
       e = launch_mac_rows_packed(a, b, w->rhat, c->dt, k, L, l, width, s, fused ? &front : nullptr);   // the same sums over the packed copy
     } else {
-      MacSection a{c->dA, d_c1, d_c1, rA, 0}, b{c->dB, d_c2, d_c2, rB, 0};
+      MacSection a{c->dA, d_c1, out_c1, rA, 0}, b{c->dB, d_c2, out_c2, rB, 0};
       e = launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s, fused ? &front : nullptr);                 // crs.rs:188-201, encryption.rs:177-200
     }
     if (e != hipSuccess) {
@@ -1491,12 +1530,23 @@ int32_t pvw_encrypt(pvw_ctx* c, const uint64_t* scalars, size_t num_scalars, con
   }
   if (rc == PVW_OK && hipMemcpyAsync(w->scalars, scalars, (size_t)c->n * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess)
     rc = fail(PVW_ERR_INTERNAL, "H2D failed");
-  if (rc == PVW_OK) rc = encrypt_enqueue(c, w, w->scalars, &dr, w->c1, w->c2, out_repr, w->stream);
-  if (rc == PVW_OK &&
+  // Output buffers the device can write (pvw_host_alloc, or memory the caller pinned / registered): the MAC stores c1 / c2
+  // straight into them, 64 bytes per (row, limb) as its workgroups finish -- the 4.7 MB of config 3 cross PCIe under the
+  // kernel instead of after it.  Pageable buffers take the copy.
+  u64 *dir1 = nullptr, *dir2 = nullptr;
+  if (rc == PVW_OK && out_repr == PVW_REPR_NTT) {
+    dir1 = (u64*)device_alias(c1_out, (size_t)c->k * P * 8);
+    dir2 = (u64*)device_alias(c2_out, (size_t)c->n * P * 8);
+    if (!dir1 || !dir2) dir1 = dir2 = nullptr;
+  }
+  if (rc == PVW_OK) rc = encrypt_enqueue(c, w, w->scalars, &dr, w->c1, w->c2, out_repr, w->stream,
+                                         dir1 ? dir1 + (size_t)c->c1_lo * P : nullptr, dir2 ? dir2 + (size_t)c->party_lo * P : nullptr);
+  if (rc == PVW_OK && !dir1 &&
       (hipMemcpyAsync(c1_out + (size_t)c->c1_lo * P, w->c1, (size_t)c->rowsA() * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
-       hipMemcpyAsync(c2_out + (size_t)c->party_lo * P, w->c2, (size_t)c->rowsB() * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
-       hipStreamSynchronize(w->stream) != hipSuccess))
+       hipMemcpyAsync(c2_out + (size_t)c->party_lo * P, w->c2, (size_t)c->rowsB() * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess))
     rc = fail(PVW_ERR_INTERNAL, "D2H failed");
+  if (hipStreamSynchronize(w->stream) != hipSuccess && rc == PVW_OK) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");
+  if (rc == PVW_OK) rc = front_check(w, w->stream);
   ws_release(c, w);
   return rc;
 }
@@ -1854,11 +1904,13 @@ int32_t pvw_decode_device(pvw_ctx* c, const uint64_t* d_noisy, size_t count, uin
 }
 
 // ------------------------------------------------------------------------ decrypt
-// noisy[d] = INTT( sum_j s-hat[j] (.) c1s[d][j] - c2col[d] )  for D ciphertexts (decryption.rs:257-274, :116): the inner
-// products as one launch, cut into ranges of j when that gives the launch enough short workgroups (decrypt_split),
-// then the inverse transform (which adds the ranges up when there are any)
-static int32_t decrypt_mac_intt(pvw_ctx* c, Workspace* w, const u64* d_c1s, const u64* d_c2col, size_t D, u64* d_noisy,
-                                hipStream_t s) {
+// noisy[d] = sum_j s-hat[j] (.) c1s[d][j] - c2col[d]  for D ciphertexts (decryption.rs:257-274): the inner products as one
+// launch, cut into ranges of j when that gives the launch enough short workgroups (decrypt_split).  Returns in
+// *ntt_domain whether d_noisy still has to be transformed back (change_representation(PowerBasis), :116): with ranges
+// the pass that adds them up (decrypt_finish) does it; without, the consumer does -- the decode kernel itself
+// (launch_decode with the transform tables) or launch_ntt.
+static int32_t decrypt_mac_only(pvw_ctx* c, Workspace* w, const u64* d_c1s, const u64* d_c2col, size_t D, u64* d_noisy,
+                                hipStream_t s, bool* ntt_domain) {
   const u32 k = c->k, l = c->l, L = c->L;
   const u32 ns = decrypt_split(k, L, l, D);
   if (ns > 1) {
@@ -1873,16 +1925,28 @@ static int32_t decrypt_mac_intt(pvw_ctx* c, Workspace* w, const u64* d_c1s, cons
     ProfScope ps(c, "decrypt_mac", s);
     PVW_HIP(launch_decrypt_mac(d_c1s, w->rhat, d_c2col, d_noisy, c->dt, k, L, l, D, s, w->dpart, ns));
   }
-  {
+  *ntt_domain = ns <= 1;
+  if (ns > 1) {
     ProfScope ps(c, "intt", s);
-    if (ns > 1) PVW_HIP(launch_decrypt_finish(w->dpart, ns, d_c2col, d_noisy, c->dt, L, l, D, s));
-    else PVW_HIP(launch_ntt(d_noisy, D, true, c->dt, L, l, s));
+    PVW_HIP(launch_decrypt_finish(w->dpart, ns, d_c2col, d_noisy, c->dt, L, l, D, s));
+  }
+  return PVW_OK;
+}
+static int32_t decrypt_mac_intt(pvw_ctx* c, Workspace* w, const u64* d_c1s, const u64* d_c2col, size_t D, u64* d_noisy,
+                                hipStream_t s) {
+  bool ntt_domain = false;
+  PVW_TRY(decrypt_mac_only(c, w, d_c1s, d_c2col, D, d_noisy, s, &ntt_domain));
+  if (ntt_domain) {
+    ProfScope ps(c, "intt", s);
+    PVW_HIP(launch_ntt(d_noisy, D, true, c->dt, c->L, c->l, s));
   }
   return PVW_OK;
 }
 
+// ntt_domain == NULL: d_noisy comes back in power basis; otherwise *ntt_domain says whether the caller (the decode) still has to
+// transform it back
 static int32_t decrypt_enqueue(pvw_ctx* c, Workspace* w, const i64* d_sk, u64* d_c1s, u64* d_c2col, size_t D,
-                               uint32_t in_repr, u64* d_noisy, hipStream_t s, bool inputs_mutable) {
+                               uint32_t in_repr, u64* d_noisy, hipStream_t s, bool inputs_mutable, bool* ntt_domain = nullptr) {
   const u32 k = c->k, l = c->l, L = c->L;
   const size_t P = c->poly();
   {
@@ -1896,6 +1960,7 @@ static int32_t decrypt_enqueue(pvw_ctx* c, Workspace* w, const i64* d_sk, u64* d
     PVW_HIP(launch_ntt(d_c1s, D * k, false, c->dt, L, l, s));
     PVW_HIP(launch_ntt(d_c2col, D, false, c->dt, L, l, s));
   }
+  if (ntt_domain) return decrypt_mac_only(c, w, d_c1s, d_c2col, D, d_noisy, s, ntt_domain);
   return decrypt_mac_intt(c, w, d_c1s, d_c2col, D, d_noisy, s);
 }
 // NTT(sk) sits in w->rhat while a decrypt runs: cleared on the call's stream behind the last kernel that read it
@@ -1938,7 +2003,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
   // chunks of about 2 GiB of ciphertext (measured: at config 5 in full, 18 GB, overlapping the decode is -7 %;
   // with 0.3 GB chunks the cross-stream events cost more than the decode they hide, +29 %): below 3 GiB in all,
   // one pass on the caller's stream.  PVW_DECRYPT_CHUNK=<dealers> overrides.
-  static const long chunk_env = PVW_ENV_INT("PVW_DECRYPT_CHUNK", 0);   // tuning build only
+  const long chunk_env = PVW_ENV_INT("PVW_DECRYPT_CHUNK", 0);   // tuning build only (read per call)
   const double total_gib = (double)D * k * P * 8 / (double)((size_t)1 << 30);
   size_t chunk = D;
   if (chunk_env >= 64) chunk = (size_t)chunk_env;

@@ -804,14 +804,15 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmSection sec, const
 // correction and the encoded scalar.  The finished l slots (8 l bytes per thread) go through the wave's own LDS rows
 // so that l / 2 neighbouring lanes write ONE row's 8 l contiguous bytes per store instead of 16 bytes each of l / 2
 // rows (API layout: rows are 8 L l bytes apart).  No block-wide barriers.
-template <int ELL>
-__global__ __launch_bounds__(256) void gemm_finish_err_kernel(GemmSection sec, DevTables t, u32 L, u32 nv, u32 nv_pad, u32 rows_pad,
+template <int ELL, int VPB>
+__global__ __launch_bounds__(32 * VPB) void gemm_finish_err_kernel(GemmSection sec, DevTables t, u32 L, u32 nv, u32 nv_pad, u32 rows_pad,
                                                                size_t ostride, const int* __restrict__ SY, size_t sy_b16, GemmErrSource es,
                                                                u32 v_lo, u32 v_hi) {
-  constexpr int VPB = 8;                                         // vectors per block (x 32 rows)
+  // VPB vectors per block (x 32 rows): 8 with the limbs cut into gridDim.z ranges (every range repeats the sampling),
+  // or 2 -- one wave -- with all limbs in one block, so that each polynomial is drawn ONCE (the launcher picks)
   constexpr int G = ELL / 2;                                     // lanes that share out one another's 8 l bytes (16 each)
   constexpr int CST = ELL + 2;                                   // LDS words per thread (16-byte aligned, bank spread)
-  __shared__ i64 coef[256 * CST];
+  __shared__ i64 coef[32 * VPB * CST];
   const u32 tid = threadIdx.x, lane = tid & 63;
   const u32 row_raw = blockIdx.x * 32 + (tid & 31), v_raw = v_lo + blockIdx.y * VPB + (tid >> 5);   // this launch: vectors [v_lo, v_hi)
   // every lane stays: a lane past the end still carries 16-byte pieces of its neighbours' rows to memory
@@ -1007,16 +1008,35 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
       // one launch per GemmErrSource of the array: es[i] covers the next es[i].span vectors (0: all that are left)
       for (u32 v_lo = 0; v_lo < nv; ++es) {
         const u32 span = es->span && es->span < nv - v_lo ? es->span : nv - v_lo, v_hi = v_lo + span;
-        const u32 gx = (sec.nrows + 31) / 32, gy = (span + 7) / 8;
-        u32 lz = 1;                                          // limb interleave: enough blocks for several rounds on the chip
-        const size_t want = (size_t)PVW_ENV_INT("PVW_FINISH_BLOCKS", 4096);   // tuning build: blocks the limb split aims at (1024 .. 16384 measured: 4096)
-        while (lz < L && (size_t)gx * gy * lz < want) lz *= 2;
-        if (lz > L) lz = L;
-        const dim3 grid(gx, gy, lz);
-        switch (ell) {
-          case 8: gemm_finish_err_kernel<8><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
-          case 16: gemm_finish_err_kernel<16><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
-          default: gemm_finish_err_kernel<32><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+        // 8 vectors per block and the limbs cut into ranges (each range repeats the sampling).  Tuning build, PVW_FINISH_VPB=2:
+        // one wave per block (32 rows x 2 vectors) sweeping ALL limbs, so that every error polynomial is drawn ONCE -- measured
+        // no better (64 dealers 0.946 vs 0.928 ms per step, key generation 4.17 vs 4.10 ms: profiles/r03_finish_ab.txt): the pass
+        // is bound by the 0.6 GB it moves (intermediate in, output out), not by the repeated ChaCha blocks.
+        const u32 gx = (sec.nrows + 31) / 32;
+        bool one_wave = false;
+#if PVW_TUNING
+        one_wave = PVW_ENV_INT("PVW_FINISH_VPB", 8) == 2;
+        if (one_wave) {
+          const dim3 grid(gx, (span + 1) / 2, 1);
+          switch (ell) {
+            case 8: gemm_finish_err_kernel<8, 2><<<grid, dim3(64), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+            case 16: gemm_finish_err_kernel<16, 2><<<grid, dim3(64), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+            default: gemm_finish_err_kernel<32, 2><<<grid, dim3(64), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+          }
+        }
+#endif
+        if (!one_wave) {
+          const u32 gy = (span + 7) / 8;
+          u32 lz = 1;                                          // limb ranges: enough blocks for several rounds on the chip
+          const size_t want = (size_t)PVW_ENV_INT("PVW_FINISH_BLOCKS", 4096);   // tuning build: blocks the limb split aims at (1024 .. 16384 measured: 4096)
+          while (lz < L && (size_t)gx * gy * lz < want) lz *= 2;
+          if (lz > L) lz = L;
+          const dim3 grid(gx, gy, lz);
+          switch (ell) {
+            case 8: gemm_finish_err_kernel<8, 8><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+            case 16: gemm_finish_err_kernel<16, 8><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+            default: gemm_finish_err_kernel<32, 8><<<grid, dim3(256), 0, s>>>(sec, t, L, nv, nv_pad, rows_pad, ostride, SY, sy_b16, *es, v_lo, v_hi); break;
+          }
         }
         v_lo = v_hi;
       }

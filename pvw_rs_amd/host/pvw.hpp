@@ -189,8 +189,15 @@ class SecretKey {
   SecretKey(std::shared_ptr<PvwParameters> p, std::vector<int64_t> c) : params(std::move(p)), secret_coeffs(std::move(c)) {}
   SecretKey(const SecretKey&) = default;
   SecretKey(SecretKey&&) = default;
-  SecretKey& operator=(const SecretKey&) = default;
-  SecretKey& operator=(SecretKey&&) = default;
+  // assignment wipes what the key held before the vector lets go of it (Zeroize, secret_key.rs:20-30)
+  SecretKey& operator=(const SecretKey& o) {
+    if (this != &o) { zeroize(); params = o.params; secret_coeffs = o.secret_coeffs; }
+    return *this;
+  }
+  SecretKey& operator=(SecretKey&& o) noexcept {
+    if (this != &o) { zeroize(); params = std::move(o.params); secret_coeffs = std::move(o.secret_coeffs); }
+    return *this;
+  }
   ~SecretKey() { zeroize(); }                                   // ZeroizeOnDrop (secret_key.rs:20-30)
   static SecretKey random(const std::shared_ptr<PvwParameters>& p, const Seed& seed, uint32_t party_index) {   // :45-63
     SecretKey s{p, std::vector<int64_t>((size_t)p->k * p->l)};

@@ -50,6 +50,8 @@ pub struct PvwRandomnessT {
     pub e2: *const i64,
 }
 
+pub const PVW_PREPARE_PACKED: u32 = 1;
+pub const PVW_PREPARE_MFMA: u32 = 2;
 pub const PVW_OK: i32 = 0;
 pub const PVW_ERR_INVALID_PARAMETERS: i32 = 1;
 pub const PVW_ERR_SAMPLING: i32 = 2;
@@ -147,6 +149,8 @@ extern "C" {
     pub fn pvw_ctx_set_profiling(ctx: *mut PvwCtx, on: i32) -> i32;
     pub fn pvw_ctx_kernel_time(ctx: *mut PvwCtx, name: *const c_char, total_ms: *mut f64, launches: *mut u64) -> i32;
     pub fn pvw_ctx_reset_profiling(ctx: *mut PvwCtx) -> i32;
+    pub fn pvw_host_alloc(bytes: usize, out: *mut *mut c_void) -> i32;
+    pub fn pvw_host_free(p: *mut c_void) -> i32;
     pub fn pvw_ctx_resident_bytes(ctx: *const PvwCtx, crs_bytes: *mut u64, pk_bytes: *mut u64) -> i32;
     pub fn pvw_ctx_derived_bytes(ctx: *const PvwCtx, packed_bytes: *mut u64, mfma_tiled_bytes: *mut u64) -> i32;
     pub fn pvw_prepare(ctx: *mut PvwCtx, flags: u32, stream: *mut c_void, bytes_out: *mut u64) -> i32;

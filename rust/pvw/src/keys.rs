@@ -109,7 +109,21 @@ impl GlobalPublicKey {
             }
             i = j;
         }
-        self.refresh_host_mirror()
+        self.refresh_host_mirror()?;
+        self.prepare_device().map(|_| ())
+    }
+
+    /// Build the device-side copies the encrypt calls stream from (`pvw_prepare`: the bit-packed copy of A-hat / B-hat
+    /// for `encrypt`, the MFMA-tiled copy for `encrypt_all_party_shares`) NOW, so that the first encrypt after a key
+    /// change neither allocates nor waits.  `&self`: the mutators above take `&mut self` (public_key.rs:214-263), so no
+    /// encrypt can be in flight while the matrices change; call this after the last `add_public_key`.
+    /// Returns the bytes allocated for the copies.
+    pub fn prepare_device(&self) -> Result<u64> {
+        let mut taken = 0u64;
+        check(unsafe {
+            sys::pvw_prepare(self.params.hip.raw(), sys::PVW_PREPARE_PACKED | sys::PVW_PREPARE_MFMA, std::ptr::null_mut(), &mut taken)
+        })?;
+        Ok(taken)
     }
 
     /// `is_full` (public_key.rs:349-351) as the device sees it.

@@ -106,8 +106,47 @@ def main():
     P.api._check(lib.pvw_decrypt_batch_device(p._h, ptr(d_sk), ptr(d_c1s), ptr(d_c2col), D, P.REPR_NTT, ptr(d_noisy_b), ptr(d_vals_b), stream))
     torch.cuda.synchronize()
     assert torch.equal(d_noisy_b, d_noisy) and torch.equal(d_vals_b, d_vals)
+    graph_capture(lib, dev)
     config5_full_size(lib, stream, dev)
     print("DEVICE_API_OK")
+
+
+def graph_capture(lib, dev):
+    """pvw_prepare, then pvw_encrypt_device captured into a graph and replayed: a captured call must not allocate,
+    synchronise or depend on per-launch host state (it takes the two-launch form of encrypt), and replays with new
+    scalars in the same buffer give that many different, correct ciphertexts."""
+    seed = bytes([0x51]) * 32
+    n, k, l, L = 70, 256, 8, 3
+    moduli = M.bench_moduli(L)
+    p = P.PvwParametersBuilder().set_parties(n).set_dimension(k).set_l(l).set_moduli(moduli).build()
+    gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, seed))
+    gpk.fill_uniform(seed)
+    s = torch.cuda.Stream(device=dev)
+    assert p.prepare(P.PREPARE_PACKED, s.cuda_stream) > 0 and p.packed_active() == 61
+    scal = torch.zeros(n, dtype=torch.int64, device=dev)
+    c1 = torch.zeros((k, L, l), dtype=torch.int64, device=dev)
+    c2 = torch.zeros((n, L, l), dtype=torch.int64, device=dev)
+    rnd = _ffi.pvw_randomness_t()
+    rnd.mode = _ffi.RND_SEED
+    C.memmove(rnd.seed, seed, 32)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        P.api._check(lib.pvw_encrypt_device(p._h, ptr(scal), n, C.byref(rnd), ptr(c1), ptr(c2), P.REPR_NTT,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for rep in range(3):
+        vals = [(rep * 1000003 + 17 * j) % (1 << 32) for j in range(n)]
+        scal.copy_(torch.tensor(vals, dtype=torch.int64))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want = P.encrypt(vals, gpk, seed)
+        assert np.array_equal(c1.cpu().numpy().view(np.uint64), want.c1), f"graph replay {rep}: c1"
+        assert np.array_equal(c2.cpu().numpy().view(np.uint64), want.c2), f"graph replay {rep}: c2"
+    # ... and the eager path on the same stream afterwards (the front's generation counters were not touched by the replays)
+    P.api._check(lib.pvw_encrypt_device(p._h, ptr(scal), n, C.byref(rnd), ptr(c1), ptr(c2), P.REPR_NTT, C.c_void_p(s.cuda_stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(c2.cpu().numpy().view(np.uint64), want.c2)
 
 
 def config5_full_size(lib, stream, dev):

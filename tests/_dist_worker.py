@@ -3,7 +3,10 @@
 mode "oracle": CPU only -- exercises the shard plan / CRS broadcast / gather plumbing of
 pvw_rs_amd.dist over gloo, with the C restatement standing in for the per-rank compute.
 mode "hip": both ranks drive the HIP path on cuda:0 (gloo for the broadcast, because two ranks
-cannot share one device under RCCL); rank 0 checks the union against an unsharded context."""
+cannot share one device under RCCL); rank 0 checks the union against an unsharded context.
+mode "nccl": ONE rank, backend "nccl" (= RCCL) on cuda:0 -- the collectives of pvw_rs_amd.dist and of bench.py
+(broadcast of the CRS as a device tensor, all_gather of the decoded shares, barrier, all_reduce(MAX)) run through
+RCCL on device tensors; more ranks need more GPUs than this pipeline's box has."""
 import os
 import sys
 
@@ -19,7 +22,15 @@ def main():
     mode, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = None
+    if mode == "nccl":
+        import torch
+        assert world == 1 and dist.is_nccl_available()
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import pvw_model as M
     import pvw_oracle as O
     from pvw_rs_amd import dist as D
@@ -35,8 +46,8 @@ def main():
     e1 = O.sample_uniform(seed, M.DOM_E1, 0, k, l, 100)
     e2 = O.sample_uniform(seed, M.DOM_E2, 0, n, l, 200)
     a_src = orc.fill_uniform(seed, M.DOM_CRS, 0, k * k).reshape(k, k, L, l) if rank == 0 else None
-    a_t = D.broadcast_crs(a_src, (k, k, L, l), src=0)                 # once, at load time
-    a_hat = a_t.numpy().view(np.uint64)
+    a_t = D.broadcast_crs(a_src, (k, k, L, l), src=0, device=dev)     # once, at load time
+    a_hat = a_t.cpu().numpy().view(np.uint64)
     b_full = orc.fill_uniform(seed, M.DOM_PK, 0, n * k).reshape(n, k, L, l)
     if mode == "oracle":
         g_hat = orc.ntt_forward(np.array([[pow(M.Params(n, k, l, moduli).delta, j, q) for j in range(l)]
@@ -60,8 +71,15 @@ def main():
     Dn = 9
     dlo, dhi = D.shard_dealers(Dn, world, rank)
     local_vals = np.arange(dlo, dhi, dtype=np.uint64) * np.uint64(3) + np.uint64(1)
-    got_all = D.all_gather_decrypted(local_vals, Dn)
+    got_all = D.all_gather_decrypted(local_vals, Dn, device=dev)
     assert got_all.tolist() == [3 * d + 1 for d in range(Dn)], got_all
+    if mode == "nccl":
+        # the rest of bench.py's collectives on device tensors: barrier, max-reduce of the elapsed time
+        import torch
+        dist.barrier()
+        t = torch.tensor([1.25 + rank], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 1.25 + (world - 1)
     c1 = D.gather_rows(c1_loc, clo, chi, k)
     c2 = D.gather_rows(c2_loc, lo, hi, n)
     if rank == 0:

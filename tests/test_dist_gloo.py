@@ -62,6 +62,33 @@ def test_world2_gloo_cpu():
 def test_world2_hip_on_one_gpu():
     _run("hip")
 
+@pytest.mark.gpu
+def test_world1_rccl_collectives_on_the_gpu():
+    # backend "nccl" IS RCCL on ROCm: one rank on cuda:0 (a child process, started before anything here touches the
+    # GPU) drives dist.broadcast_crs / load_broadcast_crs / all_gather_decrypted on device tensors, barrier and the
+    # all_reduce(MAX) of bench.py, and checks the encrypt against the unsharded oracle result
+    import torch.distributed as dist
+    if not dist.is_nccl_available():
+        pytest.skip("torch.distributed has no nccl backend")
+    _run("nccl", world=1)
+
+
+@pytest.mark.gpu
+def test_bench_forced_process_group_over_rccl():
+    # PVW_BENCH_FORCE_DIST=1: `bench.py --gpus 1` through the N > 1 code path with backend "nccl" (CRS broadcast as a
+    # device tensor, barrier, max-reduce): one line, backend recorded, same workload
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, PVW_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
+    for extra in ([], ["--path", "decrypt", "--config", "c5x16"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                            "--no-cpu", "--no-probe", "--sustain-seconds", "0"] + (extra or ["--config", "c2"]), env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["value"] > 0
 
 
 @pytest.mark.gpu

@@ -428,6 +428,43 @@ def test_prepare_builds_the_derived_copies_up_front():
         assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o)
 
 
+def test_encrypt_into_pinned_host_buffers():
+    # pvw_host_alloc: output buffers the device can write -- pvw_encrypt then has the MAC store c1 / c2 straight into them
+    # (NTT output; power-basis output and pageable buffers take the copy): same ciphertexts either way
+    import ctypes as C
+    from pvw_rs_amd import _ffi
+    run, c1o, c2o = mac_rows_case(150, 256, 8, 3)
+    p = run.params
+    lib, n, k, L, l = p._lib, 150, 256, 3, 8
+    bufs = []
+
+    def pinned(shape):
+        pp = C.c_void_p()
+        assert lib.pvw_host_alloc(int(np.prod(shape)) * 8, C.byref(pp)) == 0
+        bufs.append(pp)
+        return np.ctypeslib.as_array((C.c_uint64 * int(np.prod(shape))).from_address(pp.value)).reshape(shape)
+
+    c1p, c2p = pinned((k, L, l)), pinned((n, L, l))
+    scal = np.array([(i * 77 + 5) % (1 << 32) for i in range(n)], dtype=np.uint64)
+    rnd = _ffi.pvw_randomness_t()
+    rnd.mode = _ffi.RND_SEED
+    C.memmove(rnd.seed, SEED, 32)
+    for repr_, want in ((P.REPR_NTT, (c1o, c2o)), (P.REPR_POWER, None)):
+        c1p[:] = 0
+        c2p[:] = 0
+        rc = lib.pvw_encrypt(p._h, scal.ctypes.data_as(C.c_void_p), n, C.byref(rnd), c1p.ctypes.data_as(C.c_void_p),
+                             c2p.ctypes.data_as(C.c_void_p), repr_)
+        assert rc == 0, _ffi.last_error(lib)
+        if want is None:
+            want = (p.ntt_forward(c1p.copy()), p.ntt_forward(c2p.copy()))
+            assert np.array_equal(want[0], c1o) and np.array_equal(want[1], c2o)
+        else:
+            assert np.array_equal(c1p, want[0]) and np.array_equal(c2p, want[1])
+    del c1p, c2p
+    for pp in bufs:
+        assert lib.pvw_host_free(pp) == 0
+
+
 def test_packed_matrix_follows_key_changes_and_wide_moduli_fall_back():
     n, k, l = 24, 256, 8
     moduli = M.bench_moduli(2)

@@ -33,9 +33,10 @@ def test_tuning_build_is_selected():
 def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
     # the schedules of the tiled-stream mac_rows that are left (PVW_MAC_VARIANT: 0 by shape -- which streams the packed copy
     # where it can --, 17 not interleaved, 40 interleaved + time stamps), each with the front inside the launch and as
-    # a separate prologue launch (PVW_MAC_FRONT): the same c1, c2 (encryption.rs:158,177-200)
+    # a separate prologue launch (PVW_MAC_FRONT: 1 r-hat launch + addend producers inside the MAC launch, what ships; 0 one
+    # prologue launch for everything; 2 r-hat producers inside the MAC launch as well): the same c1, c2 (encryption.rs:158,177-200)
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for front in ("1", "0"):
+    for front in ("1", "0", "2", "1"):
         monkeypatch.setenv("PVW_MAC_FRONT", front)
         for variant in (0, 17, 40):
             monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
@@ -49,7 +50,8 @@ def test_mac_rows_packed_and_unpacked_streams_agree(n, k, l, L, monkeypatch):
     # unpacked mac_rows_kernel instead; PVW_MAC_FRONT=0: r-hat and the addends from a separate prologue launch; 44:
     # the stamped packed kernel -- same ciphertexts, all equal to the oracle's
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for packed, front, variant, width in (("1", "1", "0", 61), ("0", "1", "0", 0), ("1", "0", "0", 61), ("0", "0", "0", 0), ("1", "1", "44", 61)):
+    for packed, front, variant, width in (("1", "1", "0", 61), ("0", "1", "0", 0), ("1", "0", "0", 61), ("0", "0", "0", 0), ("1", "2", "0", 61),
+                                          ("0", "2", "0", 0), ("1", "1", "44", 61)):
         monkeypatch.setenv("PVW_MAC_PACKED", packed)
         monkeypatch.setenv("PVW_MAC_FRONT", front)
         monkeypatch.setenv("PVW_MAC_VARIANT", variant)
@@ -62,7 +64,7 @@ def test_mac_rows_packed_and_unpacked_streams_agree(n, k, l, L, monkeypatch):
 @pytest.mark.parametrize("n,k,l,moduli,width", T.MAC_PACKED_WIDTH_CASES[:7])
 def test_mac_rows_width_streams_with_a_separate_prologue(n, k, l, moduli, width, monkeypatch):
     run, c1o, c2o = T.mac_rows_case(n, k, l, None, moduli)
-    for front, variant in (("0", "0"), ("1", "44")):
+    for front, variant in (("0", "0"), ("2", "0"), ("1", "44")):
         monkeypatch.setenv("PVW_MAC_FRONT", front)
         monkeypatch.setenv("PVW_MAC_VARIANT", variant)
         ct = run()

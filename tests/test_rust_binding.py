@@ -16,7 +16,7 @@ C_TO_RUST = {
     "uint32_t": "u32", "uint32_t*": "*mut u32", "int32_t": "i32", "int32_t*": "*mut i32",
     "uint64_t": "u64", "uint64_t*": "*mut u64", "const uint64_t*": "*const u64",
     "int64_t": "i64", "int64_t*": "*mut i64", "const int64_t*": "*const i64",
-    "float": "f32", "double*": "*mut f64", "void*": "*mut c_void",
+    "float": "f32", "double*": "*mut f64", "void*": "*mut c_void", "void**": "*mut *mut c_void",
     "pvw_ctx*": "*mut PvwCtx", "const pvw_ctx*": "*const PvwCtx", "pvw_ctx**": "*mut *mut PvwCtx",
     "const pvw_params_t*": "*const PvwParamsT", "const pvw_randomness_t*": "*const PvwRandomnessT",
 }
@@ -97,7 +97,7 @@ def test_status_codes_and_constants_agree():
     c_codes = dict((k, int(v)) for k, v in re.findall(r"(PVW_(?:OK|ERR_\w+)) = (\d+)", HEADER))
     r_codes = dict((k, int(v)) for k, v in re.findall(r"pub const (PVW_(?:OK|ERR_\w+)): i32 = (\d+);", SYS))
     assert c_codes == r_codes and len(c_codes) == 20
-    for group in (r"PVW_REPR_\w+", r"PVW_RND_\w+", r"PVW_DOM_\w+"):
+    for group in (r"PVW_REPR_\w+", r"PVW_RND_\w+", r"PVW_DOM_\w+", r"PVW_PREPARE_\w+"):
         c = dict((k, int(v)) for k, v in re.findall(r"(" + group + r") = (\d+)", HEADER))
         r = dict((k, int(v)) for k, v in re.findall(r"pub const (" + group + r"): u32 = (\d+);", SYS))
         assert c == r and c, group

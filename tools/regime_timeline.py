@@ -69,6 +69,8 @@ for ci in range(contexts):
         t0 = st[:, 0].min()
         start, end = (st[:, 0] - t0) / 100.0, (st[:, 1] - t0) / 100.0
         xcc = (hw >> 28) & 0xF
+        share = (hw >> 24) & 0x7                                    # block id modulo 8
+        share_match = float((xcc == share).mean())
         spans.append(float(end.max()))
         row = []
         for x in range(8):
@@ -84,7 +86,7 @@ for ci in range(contexts):
         per_xcd.append(row)
     os.environ["PVW_MAC_VARIANT"] = "0"
     row = per_xcd[-1]
-    print(f"context {ci:2d}: mac_rows {us:6.1f} us | stamped spans {[round(s, 1) for s in spans]}")
+    print(f"context {ci:2d}: mac_rows {us:6.1f} us | stamped spans {[round(s, 1) for s in spans]} | XCC_ID == block id % 8 for {share_match * 100:.1f} % of the workgroups")
     print("    XCD:            " + " ".join(f"{x:7d}" for x in range(8)))
     print("    median wg us:   " + " ".join(f"{r[1]:7.1f}" for r in row))
     print("    runs dry at us: " + " ".join(f"{r[2]:7.1f}" for r in row))
