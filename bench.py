@@ -259,8 +259,6 @@ def main():
                      "frac_of_streamed_bytes": (streamed_bytes / mac_avg_s / 1e9 / HBM_PEAK_GBS) if mac_avg_s > 0 else 0.0,
                      "packing": (f"matrix residues stored at {width} of 64 bits ({mac_kernel}): `achieved` / `frac` count the algorithmic "
                                  "8 bytes per residue, `frac_of_streamed_bytes` the bytes the kernel reads") if packed else None,
-                     "front": "r-hat and the e1 / e2 + m g addends are made by the leading workgroups of the mac_rows launch (no separate prologue launch)"
-                              if (Dm == 0 and l <= 16 and kt["prologue"][1] == 0) else None,
                      "avg_launch_us": mac_avg_s * 1e6,
                      "launches_timed": mac_launches},
         "kernel_ms_per_step": {name: (v[0] / max(args.steps, 1)) for name, v in kt.items()},

@@ -36,8 +36,8 @@
  *     streams from (a bit-packed copy for pvw_encrypt_device, an MFMA-tiled copy
  *     for pvw_encrypt_multi_device): that call allocates up to a second copy of
  *     the resident matrices and waits for the build.  A call made while its
- *     stream is being captured into a graph never builds anything: it uses what
- *     is valid and takes the two-launch form of encrypt.
+ *     stream is being captured into a graph never builds anything: it uses the
+ *     copies that are valid (pvw_prepare first) or the plain tiled matrices.
  *     The context's own stream is created non-blocking: it is NOT ordered against
  *     the legacy default stream, so a caller that prepares or consumes the buffers
  *     on the default stream (stream 0 -- also what a framework's "current stream"

@@ -1,6 +1,6 @@
 /* pvw_hip_tuning.h -- entry points that exist ONLY in the measurement build libpvw_hip_tuning.so
  * (hipcc -DPVW_TUNING=1, pvw_rs_amd/build.py).  That build also honours the environment switches listed in
- * DESIGN.md section 7a (kernel schedule selectors such as PVW_MAC_VARIANT / PVW_MAC_PACKED / PVW_MAC_FRONT / PVW_DEC_VARIANT,
+ * DESIGN.md section 7a (kernel schedule selectors such as PVW_MAC_VARIANT / PVW_MAC_PACKED / PVW_DEC_VARIANT,
  * and the timing aids PVW_DECODE_TIMING / PVW_GEMM_ZERO_OPERANDS, which produce WRONG results by design).
  * The shipped libpvw_hip.so exports none of this and reads no environment variable: the reference samples and
  * computes unconditionally (src/crypto/encryption.rs:135-167), and so must its drop-in.

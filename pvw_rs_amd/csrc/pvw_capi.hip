@@ -117,14 +117,6 @@ struct Workspace {
   bool own_stream = false;
   u64* rhat = nullptr;       // [L][k][l]  (x4: up to four r-hat / s-hat vectors)
   size_t rhat_bytes = 0;
-  // the front of a fused encrypt launch (pvw_mac.hip): block counters and "ready" words (PVW_FRONT_* in pvw_kernels.h);
-  // they only grow, front_gen counts the launches that advanced them.  front_err: host-visible word a workgroup sets
-  // when it gives up waiting for them.
-  u32* flags = nullptr;
-  u32 front_gen = 0;
-  long front_mode = -1;          // which families the counters have been counting (a change restarts them)
-  u32* front_err = nullptr;      // host pointer (hipHostMalloc, mapped)
-  u32* front_err_dev = nullptr;  // the same word as the device sees it
   u64* dpart = nullptr;      // range sums of a split decrypt_mac [nsplit][dealers][L][l]
   size_t dpart_bytes = 0;
   u64* scalars = nullptr;    // [n]
@@ -429,11 +421,6 @@ static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
   PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
   w->rhat_bytes = 4 * k * P * 8;
   PVW_HIP(hipMemset(w->rhat, 0, w->rhat_bytes));          // recycled device memory may hold an earlier owner's data
-  PVW_HIP(hipMalloc((void**)&w->flags, (size_t)PVW_FRONT_WORDS * 4));
-  PVW_HIP(hipMemset(w->flags, 0, (size_t)PVW_FRONT_WORDS * 4));
-  PVW_HIP(hipHostMalloc((void**)&w->front_err, 64, hipHostMallocMapped));
-  *w->front_err = 0;
-  PVW_HIP(hipHostGetDevicePointer((void**)&w->front_err_dev, w->front_err, 0));
   return PVW_OK;
 }
 static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
@@ -461,8 +448,6 @@ static void ws_free(Workspace* w) {
   if (w->rhat && w->rhat_bytes) hipMemset(w->rhat, 0, w->rhat_bytes);
   if (w->scratch) hipMemset(w->scratch, 0, w->scratch_bytes);
   hipFree(w->rhat);
-  hipFree(w->flags);
-  if (w->front_err) hipHostFree(w->front_err);
   hipFree(w->dpart);
   hipFree(w->scalars);
   hipFree(w->c1);
@@ -1406,16 +1391,6 @@ static int32_t fill_encrypt_jobs(pvw_ctx* c, PrologueBatch& pb, u32 slot, u32 /*
   return PVW_OK;
 }
 
-// a workgroup of an earlier fused launch on this workspace gave up waiting for its producers (pvw_mac.hip, front):
-// report it once, bring the counters back to a known state
-static int32_t front_check(Workspace* w, hipStream_t s) {
-  if (!w->front_err || *w->front_err == 0) return PVW_OK;
-  hipStreamSynchronize(s);
-  *w->front_err = 0;
-  w->front_gen = 0;                        // the next fused launch clears the counters before it uses them
-  return fail(PVW_ERR_INTERNAL, "an encrypt launch timed out waiting for its r-hat / addend producers; its results are invalid");
-}
-
 // all pointers are device pointers; explicit r/e1/e2 are GLOBAL arrays ([k][l], [k][l], [n][l])
 // out_c1 / out_c2 != NULL: the MAC stores its results there (device-visible HOST memory of a caller whose buffers are
 // pinned) while the addends stay in d_c1 / d_c2; NTT-domain output only
@@ -1425,7 +1400,6 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
   if (!out_c1) out_c1 = d_c1;
   if (!out_c2) out_c2 = d_c2;
   if (out_repr == PVW_REPR_POWER && (out_c1 != d_c1 || out_c2 != d_c2)) return fail(PVW_ERR_INTERNAL, "direct output is NTT-domain only");
-  PVW_TRY(front_check(w, s));
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   (void)hipGetLastError();
@@ -1433,52 +1407,21 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
   const u32 width = ensure_packed(c, s, !capturing);
   PrologueBatch pb{};
   PVW_TRY(fill_encrypt_jobs(c, pb, 0, 0, rnd, d_scalars, w->rhat, d_c1, d_c2));
-  // l <= 16: r-hat is a small launch of its own and the addends are made by the leading workgroups of the MAC launch
-  // (pvw_mac.hip, front).  The launch's generation number is host-side state, so a launch that is being captured into a
-  // graph (and would be replayed with the same number) takes the two-launch form (one prologue launch for r-hat and the
-  // addends, then the MAC), as does l >= 32.  Tuning build: PVW_MAC_FRONT = 0 that form everywhere, 2 r-hat producers
-  // inside the MAC launch as well.
-  const long front_mode = l <= 16 && !capturing ? PVW_ENV_INT("PVW_MAC_FRONT", 1) : 0;
-  const bool fused = front_mode != 0;
-  MacFront front{};
-  if (fused) {
-    front.r = pb.job[0]; front.e1 = pb.job[1]; front.e2 = pb.job[2];
-    front.key = pb.key[0];
-    front.nb = front_mode == 2 ? (k + 255) / 256 : 0;
-    front.ne = (rA + rB + 63) / 64;
-    if (w->front_mode != front_mode) { w->front_mode = front_mode; w->front_gen = 0; }
-    if (w->front_gen == 0) PVW_HIP(hipMemsetAsync(w->flags, 0, (size_t)PVW_FRONT_WORDS * 4, s));
-    ++w->front_gen;
-    front.gen = w->front_gen;
-    front.target_r = w->front_gen * (L * front.nb);
-    front.target_e = w->front_gen * front.ne;
-    front.cnt_r = w->flags + PVW_FRONT_CNT_R;
-    front.cnt_e = w->flags + PVW_FRONT_CNT_E;
-    front.ready_r = w->flags + PVW_FRONT_READY_R;
-    front.ready_e = w->flags + PVW_FRONT_READY_E;
-    front.err = w->front_err_dev;
-    if (front.nb == 0) {
-      ProfScope ps(c, "prologue", s);
-      PVW_HIP(launch_front_r(front, c->dt, k, L, l, s));
-    }
-  } else {
-    pb.njobs = 3;
+  // (Round 3 measured five forms of making r-hat and / or the addends inside the MAC launch instead of in a launch in front of
+  // it: none was faster -- profiles/r03_front_ab.txt.)
+  pb.njobs = 3;
+  {
     ProfScope ps(c, "prologue", s);
     PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
   }
   {
     ProfScope ps(c, "mac_rows", s);
-    hipError_t e;
     if (width) {
       MacSection a{c->pkA, d_c1, out_c1, rA, 0}, b{c->pkB, d_c2, out_c2, rB, 0};
-      e = launch_mac_rows_packed(a, b, w->rhat, c->dt, k, L, l, width, s, fused ? &front : nullptr);   // the same sums over the packed copy
+      PVW_HIP(launch_mac_rows_packed(a, b, w->rhat, c->dt, k, L, l, width, s));   // the same sums over the packed copy
     } else {
       MacSection a{c->dA, d_c1, out_c1, rA, 0}, b{c->dB, d_c2, out_c2, rB, 0};
-      e = launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s, fused ? &front : nullptr);                 // crs.rs:188-201, encryption.rs:177-200
-    }
-    if (e != hipSuccess) {
-      if (fused) --w->front_gen;                       // nothing advanced the counters
-      return fail(PVW_ERR_INTERNAL, std::string("HIP error: ") + hipGetErrorString(e) + " at mac_rows launch");
+      PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s));                 // crs.rs:188-201, encryption.rs:177-200
     }
   }
   if (out_repr == PVW_REPR_POWER) {
@@ -1546,7 +1489,6 @@ int32_t pvw_encrypt(pvw_ctx* c, const uint64_t* scalars, size_t num_scalars, con
        hipMemcpyAsync(c2_out + (size_t)c->party_lo * P, w->c2, (size_t)c->rowsB() * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess))
     rc = fail(PVW_ERR_INTERNAL, "D2H failed");
   if (hipStreamSynchronize(w->stream) != hipSuccess && rc == PVW_OK) rc = fail(PVW_ERR_INTERNAL, "stream sync failed");
-  if (rc == PVW_OK) rc = front_check(w, w->stream);
   ws_release(c, w);
   return rc;
 }

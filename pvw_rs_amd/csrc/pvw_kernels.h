@@ -109,45 +109,16 @@ struct PrologueBatch {   // sizeof must stay below the 4 KiB kernel-argument lim
 };
 hipError_t launch_prologue(const PrologueBatch& batch, const DevTables& t, u32 L, u32 ell, hipStream_t s);
 
-// The small-polynomial work of ONE encrypt (pvw_mac.hip, "front"): r -> r-hat (encryption.rs:135-154), NTT(e1) -> the
-// c1 rows (:161-167), NTT(e2) + m g-hat -> the c2 rows (:195-196); the MAC adds onto the rows.  ne != 0: the addends are
-// made by the leading workgroups of the mac_rows launch itself; nb != 0: r-hat as well (otherwise launch_front_r, or
-// launch_prologue for everything, runs first).  nb == ne == 0: no front.
-#define PVW_FRONT_SLOTS 16            // copies of each "ready" word (a power of two)
-#define PVW_FRONT_SLOT_WORDS 256      // ... 1 KiB apart
-// layout of the workspace's front words (u32): [0] r-hat blocks done, [32] addend blocks done (both count over all launches),
-// then the ready words: r-hat copy i at PVW_FRONT_READY_R + i * PVW_FRONT_SLOT_WORDS, addend copy i behind them
-#define PVW_FRONT_CNT_R 0
-#define PVW_FRONT_CNT_E 32
-#define PVW_FRONT_READY_R 256
-#define PVW_FRONT_READY_E (PVW_FRONT_READY_R + PVW_FRONT_SLOTS * PVW_FRONT_SLOT_WORDS)
-#define PVW_FRONT_WORDS (PVW_FRONT_READY_E + PVW_FRONT_SLOTS * PVW_FRONT_SLOT_WORDS)
-struct MacFront {
-  PrologueJob r, e1, e2;     // out / strides / sampler of each family (key_idx and the rep_* fields are not used)
-  ChaChaKey key;
-  u32 nb;                    // r-hat producer blocks per limb INSIDE the MAC launch (ceil(k / 256), or 0); blocks [0, L nb)
-  u32 ne;                    // addend producer blocks inside the MAC launch, 64 polynomials each; blocks [L nb, L nb + ne)
-  u32 gen;                   // this launch's generation number (the ready words hold the last finished one)
-  u32 target_r, target_e;    // what the block counters read when this launch's producers are done
-  u32* cnt_r;                // counters and ready words (PVW_FRONT_* above)
-  u32* cnt_e;
-  u32* ready_r;
-  u32* ready_e;
-  u32* err;                  // host-visible word, set when a workgroup gave up waiting
-};
-// r-hat of `front` as a launch of its own (l <= 16)
-hipError_t launch_front_r(const MacFront& front, const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s);
-// c1 (section a: A-hat rows) and c2 (section b: B-hat rows) in a single launch; front != NULL (l <= 16): with the
-// producers it names as its first workgroups
+// c1 (section a: A-hat rows) and c2 (section b: B-hat rows) in a single launch
 hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L, u32 ell,
-                           hipStream_t s, const MacFront* front = nullptr);
+                           hipStream_t s);
 // the same over the PACKED copy of the sections (`width` bits per residue; MacSection::M = the packed copy).
 // packed_width: the stream width for a modulus chain whose widest modulus has max_q_bits bits -- 40 / 48 / 56 (k a
 // multiple of 64) or 61 (k a multiple of 256), l <= 16 -- or 0 when the geometry does not qualify.  launch_pack
 // builds the copy from the tiled matrix: packed_words(rows, ..., width) u64 per section.
 u32 packed_width(u32 max_q_bits, u32 k, u32 ell);
 hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L,
-                                  u32 ell, u32 width, hipStream_t s, const MacFront* front = nullptr);
+                                  u32 ell, u32 width, hipStream_t s);
 // *wide_flag (device word, zeroed by the caller) is set when a matrix word does not fit `width` bits: the copy is then unusable
 hipError_t launch_pack(const u64* M, u64* P, u32 rows, u32 k, u32 L, u32 ell, u32 width, u32* wide_flag, hipStream_t s);
 inline size_t packed_words(u32 rows, u32 k, u32 L, u32 ell, u32 width) {

@@ -1,7 +1,6 @@
 // pvw_mac.hip -- the streamed inner products of encrypt on gfx950 (MI355X / CDNA4): mac_rows over the tiled matrix,
-// mac_rows_packed over its bit-packed copy (what single-dealer encrypt runs), mac_rows_multi (<= 4 vectors per pass),
-// the "front" -- the small-polynomial work of one encrypt as LEADING WORKGROUPS of the same launch -- and, in the
-// measurement build, the read-bandwidth probes.
+// mac_rows_packed over its bit-packed copy (what single-dealer encrypt runs), mac_rows_multi (<= 4 vectors per pass)
+// and, in the measurement build, the read-bandwidth probes.
 //
 // Data layout in HBM
 //   "tiled matrix" M (A-hat rows followed by B-hat rows) -- the streamed operand of
@@ -56,248 +55,6 @@ __device__ __forceinline__ void stamp_end(u32 item) {
 #endif
 }
 
-// ------------------------------------------------------------------------------------
-// The front of one encrypt (MacFront, pvw_kernels.h).
-//
-// Before the streamed MAC can start, r must be sampled and transformed (encryption.rs:135-154); before a row's result
-// can be stored, its addend NTT(e1) / NTT(e2) + m g-hat must exist (:161-167, :195-196).  As ONE launch in front of
-// the MAC (prologue_kernel, pvw_poly.hip) that work is 15-18 us of latency on the critical path of a 178 us kernel that
-// is otherwise at the HBM ceiling -- and only the k polynomials of r gate the MAC; the n + k addends are needed 20 us
-// later at the earliest, when the first workgroups store.  So (the default):
-//   front_r_kernel   r-hat alone: L * ceil(k/256) blocks, one polynomial per thread, every limb's block repeating the
-//                    sampling (parallel, so it costs no latency); then the MAC launch, whose lowest block ids
-//   [0, ne)          are the addend producers: 64 polynomials of (e1 rows | e2 rows) each, every limb, and
-//   blocks above     the MAC workgroups (one per (row block, limb)) as before -- they start streaming at once.
-// Publishing: the producers' results are device-scope stores (written through to memory: nothing of them stays behind
-// in this XCD's L2); every producer wave waits for its stores, a barrier, one returning atomic add on the family's
-// counter; the block that completes the count writes the launch's generation number into PVW_FRONT_SLOTS copies of a
-// "ready" word, 1 KiB apart.
-// Waiting: nothing on a MAC workgroup's critical path.  Wave 0 requests its copy of the ready word FIRST (a device-scope
-// load: never a cached "not yet"), in front of the first 16 tile loads, and looks at it when those tiles are in: ready
-// (every workgroup but the first few hundred) -> the addend is prefetched as a two-launch encrypt does; not yet -> it is
-// waited for in the epilogue, ~20 us into the launch, when the producers have long finished (bounded spin, s_sleep in
-// between), and the addend is read then.  Only a workgroup that has SEEN the word at this launch's generation reads an
-// addend, so no ordering of block dispatch is assumed.  (A device-scope load under a saturated HBM costs 3-4 us, which
-// is why nothing on the critical path may depend on one: the forms that gated the r-hat reads on such a word -- nb != 0:
-// r-hat producers inside the MAC launch as well, kept for the tuning build as PVW_MAC_FRONT=2 -- lost more per
-// workgroup than the launch they saved: 220 vs 198 us per encrypt at config 3, profiles/r03_front_ab.txt.  A form in
-// which workgroups beyond the resident set skipped the check on a dispatch-order argument had its verification fire.)
-// The producers run at raised wave priority and fetch everything they need from memory up front: they share the chip
-// with ~450 streaming workgroups, and the first MAC workgroups cannot retire before the addends exist.
-// A spin that runs out (~1 s) raises the workspace's host-visible error word, and the call that owns the workspace
-// reports PVW_ERR_INTERNAL.  Nothing here can deadlock: producers wait for nobody and have the lowest block ids, so
-// they are dispatched before any workgroup that waits for them.  No addend line can be stale in a consumer's L2:
-// nobody reads those lines during a launch before the ready word says they are written, and the L2s are invalidated
-// between launches (the rule that makes a prologue launch's output visible to the MAC launch behind it).
-// ------------------------------------------------------------------------------------
-#define PVW_FRONT_SPIN_LIMIT (1u << 20)
-__device__ __forceinline__ bool flag_reached(u32 v, u32 target) { return (int)(v - target) >= 0; }
-__device__ __forceinline__ u32 flag_peek(const u32* flag) {        // device scope: never a cached "not yet"
-  return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// v = what flag_peek returned earlier.  Wave-uniform control flow; one wave per workgroup.
-__device__ __forceinline__ void front_wait(u32 v, const u32* flag, u32 target, u32* err) {
-  if (flag_reached((u32)__builtin_amdgcn_readfirstlane((int)v), target)) return;
-  for (u32 spins = 0;; ++spins) {
-    __builtin_amdgcn_s_sleep(16);
-    v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (flag_reached((u32)__builtin_amdgcn_readfirstlane((int)v), target)) break;
-    if (spins > PVW_FRONT_SPIN_LIMIT) {
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      break;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-// producers: every wave waits for its (device-scope, written-through) result stores, one add counts the block, the last block of
-// the family says "ready"
-__device__ __forceinline__ void front_publish(u32* cnt, u32 target, u32* ready, u32 gen) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const u32 old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == target) {
-#pragma unroll
-      for (int i = 0; i < PVW_FRONT_SLOTS; ++i)
-        __hip_atomic_store(ready + i * PVW_FRONT_SLOT_WORDS, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-// a producer's result words.  COHERENT (producers inside the MAC launch): device-scope stores -- written through to memory, so
-// that publishing needs no write-back of the XCD's whole L2 (buffer_wbl2 by every producer wave, with the L2 full of
-// streaming traffic, is what made the in-launch producers slow: profiles/r03_front_ab.txt)
-template <bool COHERENT>
-__device__ __forceinline__ void front_store2(u64* dst, u64 a, u64 b) {
-  if constexpr (COHERENT) {
-    __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(dst + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    *reinterpret_cast<v2u64*>(dst) = (v2u64){a, b};
-  }
-}
-template <int ELL>
-__device__ __forceinline__ void front_sample(const PrologueJob& job, const ChaChaKey& key, u32 local, i64* o) {
-  if (job.explicit_coeffs) {
-#pragma unroll
-    for (int s = 0; s < ELL; ++s) o[s] = job.explicit_coeffs[(size_t)local * ELL + s];
-  } else {
-    ChaChaRng g;
-    g.init(key, job.sj.domain, job.sj.index0 + local);
-    auto emit = [o](u32 s, i64 v) { o[s] = v; };
-    if (job.sj.kind == SAMPLE_CBD) sample_cbd_poly(g, ELL, job.sj.cbd_half != 0, job.sj.cbd_v, emit);
-    else sample_uniform_poly(g, ELL, job.sj.bound, emit);
-  }
-}
-// r-hat[limb] for polynomials [256 part, 256 part + 256): block b = limb * nb + part of the r-hat family.  smem: 256 * ELL
-// words of LDS.  (Also the body of front_r_kernel, the same work as a launch of its own.)
-template <int ELL, bool COHERENT>
-__device__ __forceinline__ void front_produce_r(const MacFront& f, const DevTables& t, u32 b, u32 nb, u32 k, u64* smem) {
-  const u32 tid = threadIdx.x;
-  const u32 limb = b / nb, p = (b % nb) * 256 + tid;
-  i64* o = reinterpret_cast<i64*>(smem) + (size_t)tid * ELL;
-  if (p < k) {
-    front_sample<ELL>(f.r, f.key, p, o);
-    const Mod m = t.mods[limb];
-    u64 a[ELL];
-#pragma unroll
-    for (int s = 0; s < ELL; ++s) a[s] = signed_residue(o[s], m);      // own LDS row: no barrier
-    ntt_forward<ELL>(a, t.tw + (size_t)limb * ELL, t.twp + (size_t)limb * ELL, m);
-    u64* dst = f.r.out + (size_t)limb * f.r.stride_limb + (size_t)p * f.r.stride_poly;
-#pragma unroll
-    for (int s = 0; s < ELL; s += 2) front_store2<COHERENT>(dst + s, a[s], a[s + 1]);
-  }
-}
-// addends: polynomials [64 eb, 64 eb + 64) of (e1 rows | e2 rows), all limbs.  smem: 256 * ELL words of LDS.
-// Everything the transform trips need from memory -- twiddle / gadget tables, the moduli, the 64 scalars -- is fetched into
-// LDS by waves 1-3 while wave 0 samples: one loaded-HBM latency for the block instead of one per trip.
-template <int ELL, bool COHERENT>
-__device__ __forceinline__ void front_produce_e(const MacFront& f, const DevTables& t, u32 eb, u32 L, u64* smem) {
-  const u32 tid = threadIdx.x;
-  const u32 n1 = f.e1.sj.count, total = n1 + f.e2.sj.count, gp0 = eb * 64;
-  const u32 n = L * ELL;
-  i64* sc = reinterpret_cast<i64*>(smem);                                // [64][ELL] sampled coefficients
-  u64* ssc = smem + 64 * ELL;                                            // [64] scalars (0 where the family has none)
-  u64* mq = ssc + 64;                                                    // [L][3] q, ratio_lo, ratio_hi
-  u64* tab = mq + 3 * L;                                                 // tw | twp | ghat | ghatp, [L][ELL] each
-  const bool stage = 64 * ELL + 64 + 3 * L + 4 * n <= 256 * ELL;         // everything fits behind the coefficients
-  if (tid < 64) {
-    const u32 gp = gp0 + tid;
-    if (gp < total) {
-      if (gp < n1) front_sample<ELL>(f.e1, f.key, gp, sc + (size_t)tid * ELL);
-      else front_sample<ELL>(f.e2, f.key, gp - n1, sc + (size_t)tid * ELL);
-    }
-  } else if (stage) {
-    if (tid < 128) {
-      const u32 gp = gp0 + (tid - 64);
-      u64 v = 0;
-      if (gp < total) {
-        const u64* scal = gp < n1 ? f.e1.scalars : f.e2.scalars;
-        if (scal) v = scal[gp < n1 ? gp : gp - n1];
-      }
-      ssc[tid - 64] = v;
-    } else {
-      for (u32 x = tid - 128; x < L; x += 128) {
-        const Mod m = t.mods[x];
-        mq[3 * x] = m.q;
-        mq[3 * x + 1] = m.ratio_lo;
-        mq[3 * x + 2] = m.ratio_hi;
-      }
-    }
-    for (u32 x = tid - 64; x < n; x += 192) {
-      tab[x] = t.tw[x];
-      tab[n + x] = t.twp[x];
-      tab[2 * n + x] = t.ghat[x];
-      tab[3 * n + x] = t.ghatp[x];
-    }
-  }
-  __syncthreads();
-  for (u32 idx = tid; idx < 64 * L; idx += 256) {
-    const u32 pl = idx / L, limb = idx % L, gp = gp0 + pl;
-    if (gp >= total) break;
-    const bool first = gp < n1;
-    const u32 local = first ? gp : gp - n1;
-    const u64* scal = first ? f.e1.scalars : f.e2.scalars;
-    u64* outp = first ? f.e1.out : f.e2.out;
-    const size_t sp = first ? f.e1.stride_poly : f.e2.stride_poly, sl = first ? f.e1.stride_limb : f.e2.stride_limb;
-    Mod m;
-    if (stage) { m.q = mq[3 * limb]; m.ratio_lo = mq[3 * limb + 1]; m.ratio_hi = mq[3 * limb + 2]; }
-    else m = t.mods[limb];
-    const u64* tw = stage ? tab + (size_t)limb * ELL : t.tw + (size_t)limb * ELL;
-    const u64* twp = stage ? tab + n + (size_t)limb * ELL : t.twp + (size_t)limb * ELL;
-    u64 a[ELL];
-#pragma unroll
-    for (int s = 0; s < ELL; ++s) a[s] = signed_residue(sc[(size_t)pl * ELL + s], m);
-    ntt_forward<ELL>(a, tw, twp, m);
-    if (scal) {
-      const u64 mr = signed_residue((i64)(stage ? ssc[pl] : scal[local]), m);   // `as i64` wrap, encryption.rs:195
-      const u64* g = stage ? tab + 2 * n + (size_t)limb * ELL : t.ghat + (size_t)limb * ELL;
-      const u64* gp_ = stage ? tab + 3 * n + (size_t)limb * ELL : t.ghatp + (size_t)limb * ELL;
-#pragma unroll
-      for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod_shoup(mr, g[s], gp_[s], m.q), m.q);
-    }
-    u64* dst = outp + (size_t)local * sp + (size_t)limb * sl;
-#pragma unroll
-    for (int s = 0; s < ELL; s += 2) front_store2<COHERENT>(dst + s, a[s], a[s + 1]);
-  }
-}
-// block b of a MAC launch's producers
-template <int ELL>
-__device__ __forceinline__ void front_produce(const MacFront& f, const DevTables& t, u32 b, u32 k, u32 L, u64* smem) {
-  __builtin_amdgcn_s_setprio(3);                 // ahead of the streaming waves that share the SIMD: they cannot retire before this is done
-  if (b < L * f.nb) {
-    front_produce_r<ELL, true>(f, t, b, f.nb, k, smem);
-    front_publish(f.cnt_r, f.target_r, f.ready_r, f.gen);
-  } else {
-    front_produce_e<ELL, true>(f, t, b - L * f.nb, L, smem);
-    front_publish(f.cnt_e, f.target_e, f.ready_e, f.gen);
-  }
-}
-// r-hat as a launch of its own (the default: only the addends ride inside the MAC launch, where nothing waits for them on
-// the critical path): L * ceil(k / 256) blocks of 256 threads, one polynomial per thread, every limb's block repeats
-// the sampling
-template <int ELL>
-__global__ __launch_bounds__(256) void front_r_kernel(MacFront f, DevTables t, u32 k, u32 nb) {
-  __shared__ u64 smem[256 * ELL];
-  front_produce_r<ELL, false>(f, t, blockIdx.x, nb, k, smem);
-}
-
-// ---- the MAC workgroups' side of the front ----
-struct FrontState {
-  u32 vr, ve;        // the ready words as requested at the top (wave 0)
-  u32 slot;          // word offset of this workgroup's copy
-  bool add_early;    // the addends are known to be written when the first tiles are in: prefetch as a two-launch encrypt does
-};
-// first thing a MAC workgroup does (before its tile loads)
-__device__ __forceinline__ FrontState front_begin(const MacFront& f, u32 item, u32 wave, bool has_addend) {
-  FrontState st{0, 0, 0, true};
-  if (f.nb | f.ne) {
-    st.slot = (item & (PVW_FRONT_SLOTS - 1)) * PVW_FRONT_SLOT_WORDS;
-    if (wave == 0) {
-      if (f.nb) st.vr = flag_peek(f.ready_r + st.slot);
-      if (f.ne && has_addend) st.ve = flag_peek(f.ready_e + st.slot);
-    }
-  }
-  return st;
-}
-// behind the first tile loads.  nb != 0 (tuning build): r-hat must be there before it is read -- wave 0 waits, the others
-// sit in s_barrier.  Otherwise nothing waits here: wave 0 only notes whether the addends are already written (the word
-// was requested before the tile loads, so it is in by the time they are).  Every wave of the workgroup calls this.
-__device__ __forceinline__ void front_gate(const MacFront& f, FrontState& st, u32 wave, bool has_addend) {
-  if (!(f.nb | f.ne)) return;
-  if (wave == 0) {
-    if (f.nb) front_wait(st.vr, f.ready_r + st.slot, f.gen, f.err);
-    st.add_early = !has_addend || !f.ne || flag_reached((u32)__builtin_amdgcn_readfirstlane((int)st.ve), f.gen);
-  }
-  if (f.nb) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-}
-// wave 0, before the addend is read in the epilogue when it could not be prefetched
-__device__ __forceinline__ void front_finish(const MacFront& f, const FrontState& st, bool has_addend) {
-  if (f.ne && has_addend && !st.add_early) front_wait(st.ve, f.ready_e + st.slot, f.gen, f.err);
-}
-
 // what a MAC workgroup needs to know about its output rows; shared by the three streaming kernels
 struct MacItem {
   const u64* M;
@@ -319,18 +76,12 @@ __device__ __forceinline__ MacItem mac_item(const MacSection& sa, const MacSecti
   return it;
 }
 // cross-wave sum of the four wave partials, addend, store (wave 0); `lds` holds at least 256 v2u64
-template <bool FRONT>
 __device__ __forceinline__ void mac_epilogue(v2u64* lds, const v2u64& part, const Mod& m, const MacItem& it, u32 wave, u32 lane,
-                                             u32 out_row, size_t out_o, v2u64 add_pf, const FrontState& fs, const MacFront& front) {
+                                             u32 out_row, size_t out_o, v2u64 add_pf) {
   __syncthreads();  // all waves are done with their r-hat slices
   lds[wave * 64 + lane] = part;
   __syncthreads();
   if (wave == 0) {
-    if constexpr (FRONT) {
-      front_finish(front, fs, it.addend != nullptr);
-      // first-round workgroups: the addends were still on their way when the first tiles came in
-      if (it.addend && !fs.add_early && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
-    }
     if (out_row < it.nrows) {
       v2u64 s = lds[lane];
 #pragma unroll
@@ -350,30 +101,21 @@ __device__ __forceinline__ void mac_epilogue(v2u64* lds, const v2u64& part, cons
 
 // ------------------------------------------------------------------------------------
 // mac_rows: out[row][limb][slot] = sum_j M[row][j][limb][slot] * rhat[j][limb][slot] + addend
-// grid = (front blocks +) row_blocks * L workgroups of 256 threads; the 4 waves split the j range, each streaming
+// grid = row_blocks * L workgroups of 256 threads; the 4 waves split the j range, each streaming
 // 1-KiB tiles with non-temporal loads, U in flight + U prefetched per wave; r-hat slices are staged in wave-private
 // LDS.  ILV (k % 4U == 0): the waves interleave groups of U tiles, so the workgroup reads ONE contiguous stream
 // (profiles/r01_variant_sweep.txt, r01d_mac_ilv_sweep.txt hold the sweeps that chose these schedules).
 // ------------------------------------------------------------------------------------
 template <int ELL, int U, bool ILV = false, bool STAMP = false>
-__global__ __launch_bounds__(256, ELL <= 16 ? 2 : 1) void mac_rows_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat, DevTables t,
-                                                       u32 k, u32 L, MacFront front) {
+__global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
+                                                                          const Mod* __restrict__ mods, u32 k, u32 L) {
   constexpr int NW = 4;
   constexpr int HALF = ELL / 2;   // 16-byte slot pairs per polynomial limb
   constexpr int R = 128 / ELL;    // rows per tile
   constexpr int JC = ELL <= 16 ? 64 : (ELL == 32 ? 32 : 16);  // j per staged r-hat chunk (LDS <= 32 KiB)
-  constexpr bool FRONT = ELL <= 16;                            // the producers' coefficient rows need 256 * ELL words
   __shared__ v2u64 lds[NW * JC * HALF];
   static_assert(JC * HALF >= 64, "the wave partials reuse the r-hat slabs");
-  u32 item = blockIdx.x;
-  if constexpr (FRONT) {
-    const u32 nprod = L * front.nb + front.ne;
-    if (item < nprod) {
-      front_produce<ELL>(front, t, item, k, L, reinterpret_cast<u64*>(lds));
-      return;
-    }
-    item -= nprod;
-  }
+  const u32 item = blockIdx.x;
   stamp_begin<STAMP>(item);
   const MacItem it = mac_item(sa, sb, item, L);
   const u32 limb = it.limb;
@@ -389,11 +131,6 @@ __global__ __launch_bounds__(256, ELL <= 16 ? 2 : 1) void mac_rows_kernel(MacSec
   const v2u64* rp = reinterpret_cast<const v2u64*>(rhat + (size_t)limb * k * ELL);
   v2u64* lw = lds + wave * (JC * HALF);
 
-  FrontState fs{0, 0, 0, true};
-  if constexpr (FRONT) {
-    fs = front_begin(front, item, wave, it.addend != nullptr);
-    front_gate(front, fs, wave, it.addend != nullptr);        // (this fall-back kernel waits before its first tile loads)
-  }
   const u32 out_row = it.rb * R + rho;
   const size_t out_o = (((size_t)out_row * L + limb) * ELL) / 2 + sp;
   v2u64 add_pf = (v2u64){0, 0};
@@ -415,7 +152,7 @@ __global__ __launch_bounds__(256, ELL <= 16 ? 2 : 1) void mac_rows_kernel(MacSec
     }
     // the addend of this lane's output (e1 / e2 + m*g) is requested now by the wave that will write the result: at
     // the end it would cost the workgroup one more exposed memory latency
-    if (jc == j0 && wave == 0 && it.addend && fs.add_early && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+    if (jc == j0 && wave == 0 && it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
     constexpr int RN = JC * HALF / 64;
     v2u64 rv[RN];
 #pragma unroll
@@ -464,11 +201,11 @@ __global__ __launch_bounds__(256, ELL <= 16 ? 2 : 1) void mac_rows_kernel(MacSec
     }
   }
   // one Barrett reduction per wave partial ("wavefront-wide": q, ratio are SGPRs)
-  const Mod m = t.mods[limb];
+  const Mod m = mods[limb];
   v2u64 part;
   part.x = acc_reduce(a0, m);
   part.y = acc_reduce(a1, m);
-  mac_epilogue<FRONT>(lds, part, m, it, wave, lane, out_row, out_o, add_pf, fs, front);
+  mac_epilogue(lds, part, m, it, wave, lane, out_row, out_o, add_pf);
   stamp_end<STAMP>(item);
 }
 
@@ -506,19 +243,11 @@ __device__ __forceinline__ u64 pk_get(const v2u64 (&a)[N], int bit) {
 }
 template <int ELL, bool STAMP = false>
 __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed61_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
-                                                                               DevTables t, u32 k, u32 L, MacFront front) {
+                                                                               const Mod* __restrict__ mods, u32 k, u32 L) {
   constexpr int HALF = ELL / 2, R = 128 / ELL, JC = 64, NW = 4, W = 61;
   static_assert(ELL <= 16, "one period of 64 j per r-hat slab");
   __shared__ v2u64 lds[NW * JC * HALF];
-  u32 item = blockIdx.x;
-  {
-    const u32 nprod = L * front.nb + front.ne;
-    if (item < nprod) {
-      front_produce<ELL>(front, t, item, k, L, reinterpret_cast<u64*>(lds));
-      return;
-    }
-    item -= nprod;
-  }
+  const u32 item = blockIdx.x;
   stamp_begin<STAMP>(item);
   const MacItem it = mac_item(sa, sb, item, L);
   const u32 limb = it.limb;
@@ -529,7 +258,6 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed61_kernel(
   const v2u64* Pp = reinterpret_cast<const v2u64*>(it.M) + (((size_t)it.rb * L + limb) * chunks + (size_t)wave * periods * W) * 64 + lane;
   const v2u64* rp = reinterpret_cast<const v2u64*>(rhat + (size_t)limb * k * ELL) + (size_t)wave * kq * HALF;
   v2u64* lw = lds + wave * (JC * HALF);
-  FrontState fs = front_begin(front, item, wave, it.addend != nullptr);
   const u32 out_row = it.rb * R + rho;
   const size_t out_o = (((size_t)out_row * L + limb) * ELL) / 2 + sp;
   v2u64 add_pf = (v2u64){0, 0};
@@ -540,8 +268,9 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed61_kernel(
   v2u64 xa[16], xb[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) xa[u] = ldc(u);                // group 0 of the first period
-  front_gate(front, fs, wave, it.addend != nullptr);
-  if (wave == 0 && it.addend && fs.add_early && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+  // the addend of this lane's output (e1 / e2 + m*g, written by the prologue) is requested now by the wave that will write the
+  // result: at the end it would cost the workgroup one more exposed memory latency
+  if (wave == 0 && it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
   for (u32 pd = 0; pd < periods; ++pd) {
     const u32 cb = pd * W;
     // this period's r-hat slab: 64 j x HALF sixteen-byte elements, HALF per lane
@@ -579,29 +308,21 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed61_kernel(
     group(2, xa, xb);
     group(3, xb, xa);                                          // leaves the next period's group 0 in xa
   }
-  const Mod m = t.mods[limb];
+  const Mod m = mods[limb];
   v2u64 part;
   part.x = acc_reduce(a0, m);
   part.y = acc_reduce(a1, m);
-  mac_epilogue<true>(lds, part, m, it, wave, lane, out_row, out_o, add_pf, fs, front);
+  mac_epilogue(lds, part, m, it, wave, lane, out_row, out_o, add_pf);
   stamp_end<STAMP>(item);
 }
 
 template <int ELL, int W, bool STAMP = false>
 __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packedw_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
-                                                                              DevTables t, u32 k, u32 L, MacFront front) {
+                                                                              const Mod* __restrict__ mods, u32 k, u32 L) {
   constexpr int HALF = ELL / 2, R = 128 / ELL, JC = 64, NW = 4, CG = W / 4;   // CG chunks per group of 16 j
   static_assert(ELL <= 16 && W % 4 == 0 && W < 64, "whole chunks per group");
   __shared__ v2u64 lds[NW * JC * HALF];
-  u32 item = blockIdx.x;
-  {
-    const u32 nprod = L * front.nb + front.ne;
-    if (item < nprod) {
-      front_produce<ELL>(front, t, item, k, L, reinterpret_cast<u64*>(lds));
-      return;
-    }
-    item -= nprod;
-  }
+  const u32 item = blockIdx.x;
   stamp_begin<STAMP>(item);
   const MacItem it = mac_item(sa, sb, item, L);
   const u32 limb = it.limb;
@@ -612,7 +333,6 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packedw_kernel(M
   const v2u64* Pp = reinterpret_cast<const v2u64*>(it.M) + (((size_t)it.rb * L + limb) * chunks + (size_t)wave * gw * CG) * 64 + lane;
   const v2u64* rp = reinterpret_cast<const v2u64*>(rhat + (size_t)limb * k * ELL) + (size_t)wave * kq * HALF;
   v2u64* lw = lds + wave * (JC * HALF);
-  FrontState fs = front_begin(front, item, wave, it.addend != nullptr);
   const u32 out_row = it.rb * R + rho;
   const size_t out_o = (((size_t)out_row * L + limb) * ELL) / 2 + sp;
   v2u64 add_pf = (v2u64){0, 0};
@@ -623,8 +343,9 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packedw_kernel(M
   v2u64 xa[CG], xb[CG];
 #pragma unroll
   for (int u = 0; u < CG; ++u) xa[u] = ldc(u);                // group 0
-  front_gate(front, fs, wave, it.addend != nullptr);
-  if (wave == 0 && it.addend && fs.add_early && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+  // the addend of this lane's output (e1 / e2 + m*g, written by the prologue) is requested now by the wave that will write the
+  // result: at the end it would cost the workgroup one more exposed memory latency
+  if (wave == 0 && it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
   // group g of this wave: j = 16 g .. 16 g + 15 of its range = chunks CG g .. CG g + CG - 1, residue i of the group at
   // bit W i.  Every fourth group starts a slab of (up to) 64 j of r-hat: its loads go out first, the next group's
   // chunks behind them, and only then are the slab's elements awaited and written to LDS.
@@ -664,11 +385,11 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packedw_kernel(M
     group(g, xa, xb);
     if (g + 1 < gw) group(g + 1, xb, xa);
   }
-  const Mod m = t.mods[limb];
+  const Mod m = mods[limb];
   v2u64 part;
   part.x = acc_reduce(a0, m);
   part.y = acc_reduce(a1, m);
-  mac_epilogue<true>(lds, part, m, it, wave, lane, out_row, out_o, add_pf, fs, front);
+  mac_epilogue(lds, part, m, it, wave, lane, out_row, out_o, add_pf);
   stamp_end<STAMP>(item);
 }
 
@@ -895,23 +616,13 @@ __global__ __launch_bounds__(256) void read_probe2_kernel(const u64* __restrict_
 // ------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------
-static MacFront no_front() {
-  MacFront f{};
-  return f;
-}
-template <typename K>
-static void launch_with_front(K kernel, dim3 grid, hipStream_t s, const MacSection& sa, const MacSection& sb, const u64* rhat,
-                              const DevTables& t, u32 k, u32 L, const MacFront& f) {
-  kernel<<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L, f);
-}
-// what the sections and the front add up to; false: nothing to launch
-static bool mac_grid(MacSection& sa, MacSection& sb, const MacFront& f, u32 L, u32 ell, u32& blocks) {
+// one workgroup per (row block, limb) of the two sections; false: nothing to launch
+static bool mac_grid(MacSection& sa, MacSection& sb, u32 L, u32 ell, u32& blocks) {
   const u32 R = 128 / ell;
   sa.row_blocks = (sa.nrows + R - 1) / R;
   sb.row_blocks = (sb.nrows + R - 1) / R;
-  const u32 items = (sa.row_blocks + sb.row_blocks) * L;
-  blocks = items + L * f.nb + f.ne;
-  return items != 0;
+  blocks = (sa.row_blocks + sb.row_blocks) * L;
+  return blocks != 0;
 }
 
 // PVW_MAC_VARIANT (tuning build only): 0 (default) by shape | 17 the non-interleaved schedule | 40 default + per-workgroup
@@ -920,12 +631,10 @@ static bool mac_grid(MacSection& sa, MacSection& sb, const MacFront& f, u32 L, u
 // k = 512, +2 % at n = 16384) are profiles/r01_variant_sweep.txt and r01d_mac_ilv_sweep.txt; the persistent / work-queue,
 // XCD-contiguous, 8- and 16-wave and single-buffer forms they and profiles/r02_mac_rows_timeline.txt closed are gone.
 hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L, u32 ell,
-                           hipStream_t s, const MacFront* front) {
+                           hipStream_t s) {
   MacSection sa = a, sb = b;
-  const MacFront f = front && ell <= 16 ? *front : no_front();
-  if (front && ell > 16 && front->nb) return hipErrorInvalidValue;
   u32 blocks;
-  if (!mac_grid(sa, sb, f, L, ell, blocks)) return hipSuccess;
+  if (!mac_grid(sa, sb, L, ell, blocks)) return hipSuccess;
   [[maybe_unused]] const int variant = (int)PVW_ENV_INT("PVW_MAC_VARIANT", 0);
   const dim3 grid(blocks);
   switch (ell) {
@@ -933,38 +642,29 @@ hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* 
     case 16:
 #if PVW_TUNING
       if (variant == 40 && k % 64 == 0) {
-        if (ell == 8) launch_with_front(mac_rows_kernel<8, 16, true, true>, grid, s, sa, sb, rhat, t, k, L, f);
-        else launch_with_front(mac_rows_kernel<16, 16, true, true>, grid, s, sa, sb, rhat, t, k, L, f);
+        if (ell == 8) mac_rows_kernel<8, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        else mac_rows_kernel<16, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
         break;
       }
       if (variant == 17) {
-        if (ell == 8) launch_with_front(mac_rows_kernel<8, 8>, grid, s, sa, sb, rhat, t, k, L, f);
-        else launch_with_front(mac_rows_kernel<16, 16>, grid, s, sa, sb, rhat, t, k, L, f);
+        if (ell == 8) mac_rows_kernel<8, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        else mac_rows_kernel<16, 16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
         break;
       }
 #endif
       if (k % 64 == 0) {
-        if (ell == 8) launch_with_front(mac_rows_kernel<8, 16, true>, grid, s, sa, sb, rhat, t, k, L, f);
-        else launch_with_front(mac_rows_kernel<16, 16, true>, grid, s, sa, sb, rhat, t, k, L, f);
+        if (ell == 8) mac_rows_kernel<8, 16, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        else mac_rows_kernel<16, 16, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
       } else if (ell == 8) {
-        launch_with_front(mac_rows_kernel<8, 8>, grid, s, sa, sb, rhat, t, k, L, f);
+        mac_rows_kernel<8, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
       } else {
-        launch_with_front(mac_rows_kernel<16, 16>, grid, s, sa, sb, rhat, t, k, L, f);
+        mac_rows_kernel<16, 16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
       }
       break;
-    case 32: launch_with_front(mac_rows_kernel<32, 8>, grid, s, sa, sb, rhat, t, k, L, f); break;
-    case 64: launch_with_front(mac_rows_kernel<64, 8>, grid, s, sa, sb, rhat, t, k, L, f); break;
+    case 32: mac_rows_kernel<32, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L); break;
+    case 64: mac_rows_kernel<64, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L); break;
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
-}
-
-hipError_t launch_front_r(const MacFront& front, const DevTables& t, u32 k, u32 L, u32 ell, hipStream_t s) {
-  const u32 nb = (k + 255) / 256;
-  if (k == 0) return hipSuccess;
-  if (ell == 8) front_r_kernel<8><<<dim3(L * nb), dim3(256), 0, s>>>(front, t, k, nb);
-  else if (ell == 16) front_r_kernel<16><<<dim3(L * nb), dim3(256), 0, s>>>(front, t, k, nb);
-  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
@@ -977,29 +677,28 @@ u32 packed_width(u32 max_q_bits, u32 k, u32 ell) {
 }
 
 hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, const u64* rhat, const DevTables& t, u32 k, u32 L,
-                                  u32 ell, u32 width, hipStream_t s, const MacFront* front) {
+                                  u32 ell, u32 width, hipStream_t s) {
   if (ell > 16 || width == 0 || (width == 61 ? k % 256 != 0 : (k % 64 != 0 || width % 4 != 0))) return hipErrorInvalidValue;
   MacSection sa = a, sb = b;
-  const MacFront f = front ? *front : no_front();
   u32 blocks;
-  if (!mac_grid(sa, sb, f, L, ell, blocks)) return hipSuccess;
+  if (!mac_grid(sa, sb, L, ell, blocks)) return hipSuccess;
   const dim3 grid(blocks);
 #define PVW_PACKEDW(Wv)                                                                                   \
   do {                                                                                                    \
     if (stamp) {                                                                                          \
-      if (ell == 8) launch_with_front(mac_rows_packedw_kernel<8, Wv, PVW_TUNING != 0>, grid, s, sa, sb, rhat, t, k, L, f);   \
-      else launch_with_front(mac_rows_packedw_kernel<16, Wv, PVW_TUNING != 0>, grid, s, sa, sb, rhat, t, k, L, f);           \
-    } else if (ell == 8) launch_with_front(mac_rows_packedw_kernel<8, Wv>, grid, s, sa, sb, rhat, t, k, L, f);   \
-    else launch_with_front(mac_rows_packedw_kernel<16, Wv>, grid, s, sa, sb, rhat, t, k, L, f);                  \
+      if (ell == 8) mac_rows_packedw_kernel<8, Wv, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);   \
+      else mac_rows_packedw_kernel<16, Wv, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);           \
+    } else if (ell == 8) mac_rows_packedw_kernel<8, Wv><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);   \
+    else mac_rows_packedw_kernel<16, Wv><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);                  \
   } while (0)
   const bool stamp = PVW_TUNING && PVW_ENV_INT("PVW_MAC_VARIANT", 0) == 44;   // per-workgroup time stamps (tools/mac_timeline.py c3 44)
   switch (width) {
     case 61:
       if (stamp) {
-        if (ell == 8) launch_with_front(mac_rows_packed61_kernel<8, PVW_TUNING != 0>, grid, s, sa, sb, rhat, t, k, L, f);
-        else launch_with_front(mac_rows_packed61_kernel<16, PVW_TUNING != 0>, grid, s, sa, sb, rhat, t, k, L, f);
-      } else if (ell == 8) launch_with_front(mac_rows_packed61_kernel<8>, grid, s, sa, sb, rhat, t, k, L, f);
-      else launch_with_front(mac_rows_packed61_kernel<16>, grid, s, sa, sb, rhat, t, k, L, f);
+        if (ell == 8) mac_rows_packed61_kernel<8, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        else mac_rows_packed61_kernel<16, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+      } else if (ell == 8) mac_rows_packed61_kernel<8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+      else mac_rows_packed61_kernel<16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
       break;
     case 56: PVW_PACKEDW(56); break;
     case 48: PVW_PACKEDW(48); break;

@@ -112,9 +112,8 @@ def main():
 
 
 def graph_capture(lib, dev):
-    """pvw_prepare, then pvw_encrypt_device captured into a graph and replayed: a captured call must not allocate,
-    synchronise or depend on per-launch host state (it takes the two-launch form of encrypt), and replays with new
-    scalars in the same buffer give that many different, correct ciphertexts."""
+    """pvw_prepare, then pvw_encrypt_device captured into a graph and replayed: a captured call must not allocate or
+    synchronise, and replays with new scalars in the same buffer give that many different, correct ciphertexts."""
     seed = bytes([0x51]) * 32
     n, k, l, L = 70, 256, 8, 3
     moduli = M.bench_moduli(L)
@@ -143,7 +142,7 @@ def graph_capture(lib, dev):
         want = P.encrypt(vals, gpk, seed)
         assert np.array_equal(c1.cpu().numpy().view(np.uint64), want.c1), f"graph replay {rep}: c1"
         assert np.array_equal(c2.cpu().numpy().view(np.uint64), want.c2), f"graph replay {rep}: c2"
-    # ... and the eager path on the same stream afterwards (the front's generation counters were not touched by the replays)
+    # ... and the eager path on the same stream afterwards
     P.api._check(lib.pvw_encrypt_device(p._h, ptr(scal), n, C.byref(rnd), ptr(c1), ptr(c2), P.REPR_NTT, C.c_void_p(s.cuda_stream)))
     torch.cuda.synchronize()
     assert np.array_equal(c2.cpu().numpy().view(np.uint64), want.c2)

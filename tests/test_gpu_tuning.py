@@ -32,43 +32,38 @@ def test_tuning_build_is_selected():
 @pytest.mark.parametrize("n,k,l,L", T.MAC_SCHEDULE_CASES + [(20, 512, 8, 2), (10, 256, 16, 2), (3000, 256, 16, 4)])
 def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
     # the schedules of the tiled-stream mac_rows that are left (PVW_MAC_VARIANT: 0 by shape -- which streams the packed copy
-    # where it can --, 17 not interleaved, 40 interleaved + time stamps), each with the front inside the launch and as
-    # a separate prologue launch (PVW_MAC_FRONT: 1 r-hat launch + addend producers inside the MAC launch, what ships; 0 one
-    # prologue launch for everything; 2 r-hat producers inside the MAC launch as well): the same c1, c2 (encryption.rs:158,177-200)
+    # where it can --, 17 not interleaved, 40 interleaved + time stamps): the same c1, c2 (encryption.rs:158,177-200)
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for front in ("1", "0", "2", "1"):
-        monkeypatch.setenv("PVW_MAC_FRONT", front)
-        for variant in (0, 17, 40):
-            monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
-            ct = run()
-            assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (front, variant)
+    for variant in (0, 17, 40):
+        monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
+        ct = run()
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
 
 
 @pytest.mark.parametrize("n,k,l,L", T.MAC_PACKED_CASES)
 def test_mac_rows_packed_and_unpacked_streams_agree(n, k, l, L, monkeypatch):
     # PVW_MAC_PACKED=0: the geometries the shipped library streams from the 61-bit packed copy, served by the
-    # unpacked mac_rows_kernel instead; PVW_MAC_FRONT=0: r-hat and the addends from a separate prologue launch; 44:
-    # the stamped packed kernel -- same ciphertexts, all equal to the oracle's
+    # unpacked mac_rows_kernel instead; 44: the stamped packed kernel -- same ciphertexts, all equal to the oracle's
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for packed, front, variant, width in (("1", "1", "0", 61), ("0", "1", "0", 0), ("1", "0", "0", 61), ("0", "0", "0", 0), ("1", "2", "0", 61),
-                                          ("0", "2", "0", 0), ("1", "1", "44", 61)):
+    for packed, variant, width in (("1", "0", 61), ("0", "0", 0), ("1", "44", 61)):
         monkeypatch.setenv("PVW_MAC_PACKED", packed)
-        monkeypatch.setenv("PVW_MAC_FRONT", front)
         monkeypatch.setenv("PVW_MAC_VARIANT", variant)
         ct = run()
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (packed, front, variant)
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (packed, variant)
         if packed == "1":
             assert run.params.packed_active() == width
 
 
 @pytest.mark.parametrize("n,k,l,moduli,width", T.MAC_PACKED_WIDTH_CASES[:7])
-def test_mac_rows_width_streams_with_a_separate_prologue(n, k, l, moduli, width, monkeypatch):
+def test_mac_rows_width_streams_stamped_and_unpacked(n, k, l, moduli, width, monkeypatch):
+    # the 40 / 48 / 56-bit streams with per-workgroup time stamps (44), and the same geometry from the tiled matrices
     run, c1o, c2o = T.mac_rows_case(n, k, l, None, moduli)
-    for front, variant in (("0", "0"), ("2", "0"), ("1", "44")):
-        monkeypatch.setenv("PVW_MAC_FRONT", front)
+    for packed, variant in (("1", "44"), ("0", "0"), ("1", "0")):
+        monkeypatch.setenv("PVW_MAC_PACKED", packed)
         monkeypatch.setenv("PVW_MAC_VARIANT", variant)
         ct = run()
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o) and run.params.packed_active() == width
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (packed, variant)
+    assert run.params.packed_active() == width
 
 
 @pytest.mark.parametrize("k,l,L,D", T.DECRYPT_SHAPE_CASES)
@@ -138,7 +133,7 @@ def test_switches_exist_only_in_the_tuning_build(monkeypatch):
         return ct.c1.copy(), ct.c2.copy(), p.packed_active()
     want = once("default")
     assert want[2] == 61 and once("tuning")[2] == 61
-    for name, val in (("PVW_MAC_PACKED", "0"), ("PVW_MAC_FRONT", "0"), ("PVW_DECODE_TIMING", "1"), ("PVW_GEMM_ZERO_OPERANDS", "1"), ("PVW_MAC_VARIANT", "17")):
+    for name, val in (("PVW_MAC_PACKED", "0"), ("PVW_DECODE_TIMING", "1"), ("PVW_GEMM_ZERO_OPERANDS", "1"), ("PVW_MAC_VARIANT", "17")):
         monkeypatch.setenv(name, val)
     got = once("default")
     assert all(np.array_equal(a, b) for a, b in zip(got[:2], want[:2])) and got[2] == 61, "the shipped library reacted to a tuning variable"
