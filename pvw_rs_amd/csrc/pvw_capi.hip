@@ -117,6 +117,7 @@ struct Workspace {
   bool own_stream = false;
   u64* rhat = nullptr;       // [L][k][l]  (x4: up to four r-hat / s-hat vectors)
   size_t rhat_bytes = 0;
+  i64* esmall = nullptr;     // [rowsA + rowsB][l] sampled e1 | e2 coefficients of one encrypt (compact addends, l <= 16)
   u64* dpart = nullptr;      // range sums of a split decrypt_mac [nsplit][dealers][L][l]
   size_t dpart_bytes = 0;
   u64* scalars = nullptr;    // [n]
@@ -421,6 +422,7 @@ static int32_t ws_alloc(pvw_ctx* c, Workspace* w) {
   PVW_HIP(hipMalloc((void**)&w->rhat, 4 * k * P * 8));   // up to 4 r-hat / s-hat vectors (mac_rows_multi)
   w->rhat_bytes = 4 * k * P * 8;
   PVW_HIP(hipMemset(w->rhat, 0, w->rhat_bytes));          // recycled device memory may hold an earlier owner's data
+  if (c->l <= 16) PVW_HIP(hipMalloc((void**)&w->esmall, ((size_t)c->rowsA() + c->rowsB()) * c->l * 8 + 16));
   return PVW_OK;
 }
 static int32_t ws_host_buffers(pvw_ctx* c, Workspace* w) {
@@ -448,6 +450,7 @@ static void ws_free(Workspace* w) {
   if (w->rhat && w->rhat_bytes) hipMemset(w->rhat, 0, w->rhat_bytes);
   if (w->scratch) hipMemset(w->scratch, 0, w->scratch_bytes);
   hipFree(w->rhat);
+  hipFree(w->esmall);
   hipFree(w->dpart);
   hipFree(w->scalars);
   hipFree(w->c1);
@@ -1407,22 +1410,42 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
   const u32 width = ensure_packed(c, s, !capturing);
   PrologueBatch pb{};
   PVW_TRY(fill_encrypt_jobs(c, pb, 0, 0, rnd, d_scalars, w->rhat, d_c1, d_c2));
-  // (Round 3 measured five forms of making r-hat and / or the addends inside the MAC launch instead of in a launch in front of
-  // it: none was faster -- profiles/r03_front_ab.txt.)
-  pb.njobs = 3;
+  // l <= 16: the addends travel in COMPACT form -- the prologue transforms r only and leaves the sampled e1 / e2 coefficients as
+  // they are (8 l bytes per row instead of 8 L l written and read back); the MAC workgroups transform their own rows' e and add
+  // m g-hat (MacSection::e_small, mac_small_addend).  Explicit randomness: the caller's e1 / e2 arrays ARE the compact form.
+  // (Round 3 also measured five forms of making r-hat and / or the addends inside the MAC launch instead of in a launch in front
+  // of it: none was faster -- profiles/r03_front_ab.txt.)  Tuning build: PVW_MAC_COMPACT=0 the round-2 form (full addends).
+  const bool compact = l <= 16 && w->esmall && PVW_ENV_INT("PVW_MAC_COMPACT", 1) != 0;
+  const i64 *es1 = nullptr, *es2 = nullptr;
+  if (compact) {
+    if (rnd->mode == PVW_RND_EXPLICIT) {
+      es1 = pb.job[1].explicit_coeffs;
+      es2 = pb.job[2].explicit_coeffs;
+      pb.njobs = 1;                                   // r only
+    } else {
+      pb.job[1].raw_out = w->esmall;
+      pb.job[2].raw_out = w->esmall + (size_t)rA * l;
+      es1 = pb.job[1].raw_out;
+      es2 = pb.job[2].raw_out;
+      pb.njobs = 3;
+    }
+  } else {
+    pb.njobs = 3;
+  }
   {
     ProfScope ps(c, "prologue", s);
     PVW_HIP(launch_prologue(pb, c->dt, L, l, s));
   }
   {
     ProfScope ps(c, "mac_rows", s);
-    if (width) {
-      MacSection a{c->pkA, d_c1, out_c1, rA, 0}, b{c->pkB, d_c2, out_c2, rB, 0};
-      PVW_HIP(launch_mac_rows_packed(a, b, w->rhat, c->dt, k, L, l, width, s));   // the same sums over the packed copy
-    } else {
-      MacSection a{c->dA, d_c1, out_c1, rA, 0}, b{c->dB, d_c2, out_c2, rB, 0};
-      PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s));                 // crs.rs:188-201, encryption.rs:177-200
+    MacSection a{width ? c->pkA : c->dA, compact ? nullptr : d_c1, out_c1, rA, 0}, b{width ? c->pkB : c->dB, compact ? nullptr : d_c2, out_c2, rB, 0};
+    if (compact) {
+      a.e_small = es1;
+      b.e_small = es2;
+      b.scalars = d_scalars + c->party_lo;
     }
+    if (width) PVW_HIP(launch_mac_rows_packed(a, b, w->rhat, c->dt, k, L, l, width, s));   // the same sums over the packed copy
+    else PVW_HIP(launch_mac_rows(a, b, w->rhat, c->dt, k, L, l, s));                       // crs.rs:188-201, encryption.rs:177-200
   }
   if (out_repr == PVW_REPR_POWER) {
     ProfScope ps(c, "intt", s);

@@ -63,6 +63,12 @@ struct MacSection {
   u64* out;
   u32 nrows;
   u32 row_blocks;
+  // l <= 16: the addend of row i in COMPACT form instead of `addend` -- the l small coefficients of its error polynomial
+  // (e_small[i][l], as sampled or as the caller supplied them) and, for c2 rows, the scalar m_i (scalars[i]; NULL: none).
+  // The kernel transforms them itself (NTT(e_i) + m_i g-hat for its limb: encryption.rs:161-167, :195-196) -- 8 l + 8
+  // bytes per row cross memory instead of 8 L l written by the prologue and read back here.
+  const i64* e_small = nullptr;
+  const u64* scalars = nullptr;
 };
 // group != 0: polynomial p goes to out + (p / group) * stride_group + (p % group) * stride_poly
 hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t stride_poly,
@@ -93,6 +99,9 @@ struct PrologueJob {
   u32 rep_key;        // 0: every replica shares the key, 1: one key per replica
   u32 rep_index0;     // stream index offset per replica
   size_t rep_out, rep_scalars, rep_coeffs;   // element offsets per replica
+  // not NULL: the family is only SAMPLED -- polynomial p's l coefficients go to raw_out[p * l ..] as they are (no reduction, no
+  // transform; `out`, `scalars` and the strides are not used).  Single replica only.
+  i64* raw_out;
 };
 #define PVW_MAX_PROLOGUE_JOBS 8
 #define PVW_MAX_PROLOGUE_KEYS 64

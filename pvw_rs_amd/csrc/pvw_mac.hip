@@ -60,7 +60,10 @@ struct MacItem {
   const u64* M;
   const u64* addend;
   u64* out;
+  const i64* e_small;      // compact addends (MacSection): small coefficients per row ...
+  const u64* scalars;      // ... and the row's scalar
   u32 nrows, rb, limb;
+  __device__ __forceinline__ bool has_addend() const { return addend != nullptr || e_small != nullptr; }
 };
 __device__ __forceinline__ MacItem mac_item(const MacSection& sa, const MacSection& sb, u32 item, u32 L) {
   // section a = A-hat rows (c1), section b = B-hat rows (c2): one launch covers both
@@ -72,8 +75,63 @@ __device__ __forceinline__ MacItem mac_item(const MacSection& sa, const MacSecti
   it.M = in_a ? sa.M : sb.M;
   it.addend = in_a ? sa.addend : sb.addend;
   it.out = in_a ? sa.out : sb.out;
+  it.e_small = in_a ? sa.e_small : sb.e_small;
+  it.scalars = in_a ? sa.scalars : sb.scalars;
   it.nrows = in_a ? sa.nrows : sb.nrows;
   return it;
+}
+// Wave 0 of a MAC workgroup makes its rows' addends from the compact form (MacSection::e_small / scalars): lane i < R
+// fetches row i's l small coefficients and scalar at the top of the kernel (mac_small_fetch: the loads ride with the first
+// tile loads) and, AFTER its share of the inner products, reduces them mod this workgroup's modulus, transforms them
+// (l-point NTT in registers) and adds m_i g-hat (encryption.rs:161-167, :195-196; encode_scalar parameters.rs:346-367) --
+// ~250 instructions on R lanes -- then the wave redistributes through `adl` (R * ELL words of LDS) and every lane gets its
+// (row rho, slot pair sp) pair.  Bit-identical to what the prologue launch would have written as the addend.  (Doing it at
+// the top instead, before wave 0's first MAC, cost 2.5 us per round of workgroups: the coefficients arrive no earlier than
+// the tiles, and the transform then stands between the tiles and their MACs.)
+template <int ELL>
+struct SmallAddend {
+  v2u64 e[ELL / 2];
+  u64 m;
+};
+template <int ELL>
+__device__ __forceinline__ void mac_small_fetch(const MacItem& it, u32 lane, SmallAddend<ELL>& sa) {
+  constexpr int R = 128 / ELL;
+  const u32 row = it.rb * R + lane;
+  sa.m = 0;
+#pragma unroll
+  for (int s = 0; s < ELL / 2; ++s) sa.e[s] = (v2u64){0, 0};
+  if (lane < (u32)R && row < it.nrows) {
+    const v2u64* src = reinterpret_cast<const v2u64*>(it.e_small + (size_t)row * ELL);
+#pragma unroll
+    for (int s = 0; s < ELL / 2; ++s) sa.e[s] = src[s];
+    if (it.scalars) sa.m = it.scalars[row];
+  }
+}
+template <int ELL>
+__device__ __forceinline__ v2u64 mac_small_make(const MacItem& it, const DevTables& t, const Mod& m, const SmallAddend<ELL>& sa, u32 lane,
+                                                u32 rho, u32 sp, u64* adl) {
+  constexpr int R = 128 / ELL;
+  if (lane < (u32)R) {
+    u64 a[ELL];
+#pragma unroll
+    for (int s = 0; s < ELL / 2; ++s) {
+      a[2 * s] = signed_residue((i64)sa.e[s].x, m);
+      a[2 * s + 1] = signed_residue((i64)sa.e[s].y, m);
+    }
+    ntt_forward<ELL>(a, t.tw + (size_t)it.limb * ELL, t.twp + (size_t)it.limb * ELL, m);
+    if (it.scalars) {
+      const u64 mr = signed_residue((i64)sa.m, m);                       // `as i64` wrap, encryption.rs:195
+      const u64* g = t.ghat + (size_t)it.limb * ELL;
+      const u64* gp = t.ghatp + (size_t)it.limb * ELL;
+#pragma unroll
+      for (int s = 0; s < ELL; ++s) a[s] = addmod(a[s], mulmod_shoup(mr, g[s], gp[s], m.q), m.q);
+    }
+#pragma unroll
+    for (int s = 0; s < ELL; s += 2) *reinterpret_cast<v2u64*>(adl + lane * ELL + s) = (v2u64){a[s], a[s + 1]};
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return *reinterpret_cast<const v2u64*>(adl + rho * ELL + 2 * sp);      // (rows past the section's end are never stored)
 }
 // cross-wave sum of the four wave partials, addend, store (wave 0); `lds` holds at least 256 v2u64
 __device__ __forceinline__ void mac_epilogue(v2u64* lds, const v2u64& part, const Mod& m, const MacItem& it, u32 wave, u32 lane,
@@ -90,7 +148,7 @@ __device__ __forceinline__ void mac_epilogue(v2u64* lds, const v2u64& part, cons
         s.x = addmod(s.x, tq.x, m.q);
         s.y = addmod(s.y, tq.y, m.q);
       }
-      if (it.addend) {
+      if (it.has_addend()) {
         s.x = addmod(s.x, add_pf.x, m.q);
         s.y = addmod(s.y, add_pf.y, m.q);
       }
@@ -107,13 +165,13 @@ __device__ __forceinline__ void mac_epilogue(v2u64* lds, const v2u64& part, cons
 // (profiles/r01_variant_sweep.txt, r01d_mac_ilv_sweep.txt hold the sweeps that chose these schedules).
 // ------------------------------------------------------------------------------------
 template <int ELL, int U, bool ILV = false, bool STAMP = false>
-__global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
-                                                                          const Mod* __restrict__ mods, u32 k, u32 L) {
+__global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat, DevTables t, u32 k, u32 L) {
   constexpr int NW = 4;
   constexpr int HALF = ELL / 2;   // 16-byte slot pairs per polynomial limb
   constexpr int R = 128 / ELL;    // rows per tile
   constexpr int JC = ELL <= 16 ? 64 : (ELL == 32 ? 32 : 16);  // j per staged r-hat chunk (LDS <= 32 KiB)
   __shared__ v2u64 lds[NW * JC * HALF];
+  __shared__ u64 adl[ELL <= 16 ? 128 : 1];                    // compact addends of the workgroup's rows (mac_small_addend)
   static_assert(JC * HALF >= 64, "the wave partials reuse the r-hat slabs");
   const u32 item = blockIdx.x;
   stamp_begin<STAMP>(item);
@@ -134,6 +192,7 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
   const u32 out_row = it.rb * R + rho;
   const size_t out_o = (((size_t)out_row * L + limb) * ELL) / 2 + sp;
   v2u64 add_pf = (v2u64){0, 0};
+  SmallAddend<(ELL <= 16 ? ELL : 2)> small;
 
   Acc a0, a1;
   acc_zero(a0);
@@ -150,9 +209,15 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
 #pragma unroll
       for (int u = 0; u < U; ++u) x[u] = ld(u);
     }
-    // the addend of this lane's output (e1 / e2 + m*g) is requested now by the wave that will write the result: at
-    // the end it would cost the workgroup one more exposed memory latency
-    if (jc == j0 && wave == 0 && it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+    // the addend of this lane's output is made (compact form, l <= 16) or requested (e1 / e2 + m*g written by the prologue) now,
+    // by the wave that will write the result: at the end it would cost the workgroup one more exposed memory latency
+    if (jc == j0 && wave == 0) {
+      bool fetched = false;
+      if constexpr (ELL <= 16) {
+        if (it.e_small) { mac_small_fetch<ELL>(it, lane, small); fetched = true; }
+      }
+      if (!fetched && it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+    }
     constexpr int RN = JC * HALF / 64;
     v2u64 rv[RN];
 #pragma unroll
@@ -201,7 +266,10 @@ __global__ __launch_bounds__(256) void mac_rows_kernel(MacSection sa, MacSection
     }
   }
   // one Barrett reduction per wave partial ("wavefront-wide": q, ratio are SGPRs)
-  const Mod m = mods[limb];
+  const Mod m = t.mods[limb];
+  if constexpr (ELL <= 16) {
+    if (wave == 0 && it.e_small) add_pf = mac_small_make<ELL>(it, t, m, small, lane, rho, sp, adl);
+  }
   v2u64 part;
   part.x = acc_reduce(a0, m);
   part.y = acc_reduce(a1, m);
@@ -243,10 +311,11 @@ __device__ __forceinline__ u64 pk_get(const v2u64 (&a)[N], int bit) {
 }
 template <int ELL, bool STAMP = false>
 __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed61_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
-                                                                               const Mod* __restrict__ mods, u32 k, u32 L) {
+                                                                               DevTables t, u32 k, u32 L) {
   constexpr int HALF = ELL / 2, R = 128 / ELL, JC = 64, NW = 4, W = 61;
   static_assert(ELL <= 16, "one period of 64 j per r-hat slab");
   __shared__ v2u64 lds[NW * JC * HALF];
+  __shared__ u64 adl[128];                                    // compact addends of the workgroup's rows (mac_small_addend)
   const u32 item = blockIdx.x;
   stamp_begin<STAMP>(item);
   const MacItem it = mac_item(sa, sb, item, L);
@@ -268,9 +337,13 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed61_kernel(
   v2u64 xa[16], xb[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) xa[u] = ldc(u);                // group 0 of the first period
-  // the addend of this lane's output (e1 / e2 + m*g, written by the prologue) is requested now by the wave that will write the
-  // result: at the end it would cost the workgroup one more exposed memory latency
-  if (wave == 0 && it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+  // the addend of this lane's output is made (compact form) or requested (e1 / e2 + m*g written by the prologue) now, by the
+  // wave that will write the result: at the end it would cost the workgroup one more exposed memory latency
+  SmallAddend<ELL> small;
+  if (wave == 0) {
+    if (it.e_small) mac_small_fetch<ELL>(it, lane, small);
+    else if (it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+  }
   for (u32 pd = 0; pd < periods; ++pd) {
     const u32 cb = pd * W;
     // this period's r-hat slab: 64 j x HALF sixteen-byte elements, HALF per lane
@@ -308,7 +381,8 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed61_kernel(
     group(2, xa, xb);
     group(3, xb, xa);                                          // leaves the next period's group 0 in xa
   }
-  const Mod m = mods[limb];
+  const Mod m = t.mods[limb];
+  if (wave == 0 && it.e_small) add_pf = mac_small_make<ELL>(it, t, m, small, lane, rho, sp, adl);
   v2u64 part;
   part.x = acc_reduce(a0, m);
   part.y = acc_reduce(a1, m);
@@ -318,10 +392,11 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packed61_kernel(
 
 template <int ELL, int W, bool STAMP = false>
 __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packedw_kernel(MacSection sa, MacSection sb, const u64* __restrict__ rhat,
-                                                                              const Mod* __restrict__ mods, u32 k, u32 L) {
+                                                                              DevTables t, u32 k, u32 L) {
   constexpr int HALF = ELL / 2, R = 128 / ELL, JC = 64, NW = 4, CG = W / 4;   // CG chunks per group of 16 j
   static_assert(ELL <= 16 && W % 4 == 0 && W < 64, "whole chunks per group");
   __shared__ v2u64 lds[NW * JC * HALF];
+  __shared__ u64 adl[128];                                    // compact addends of the workgroup's rows (mac_small_addend)
   const u32 item = blockIdx.x;
   stamp_begin<STAMP>(item);
   const MacItem it = mac_item(sa, sb, item, L);
@@ -343,9 +418,13 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packedw_kernel(M
   v2u64 xa[CG], xb[CG];
 #pragma unroll
   for (int u = 0; u < CG; ++u) xa[u] = ldc(u);                // group 0
-  // the addend of this lane's output (e1 / e2 + m*g, written by the prologue) is requested now by the wave that will write the
-  // result: at the end it would cost the workgroup one more exposed memory latency
-  if (wave == 0 && it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+  // the addend of this lane's output is made (compact form) or requested (e1 / e2 + m*g written by the prologue) now, by the
+  // wave that will write the result: at the end it would cost the workgroup one more exposed memory latency
+  SmallAddend<ELL> small;
+  if (wave == 0) {
+    if (it.e_small) mac_small_fetch<ELL>(it, lane, small);
+    else if (it.addend && out_row < it.nrows) add_pf = reinterpret_cast<const v2u64*>(it.addend)[out_o];
+  }
   // group g of this wave: j = 16 g .. 16 g + 15 of its range = chunks CG g .. CG g + CG - 1, residue i of the group at
   // bit W i.  Every fourth group starts a slab of (up to) 64 j of r-hat: its loads go out first, the next group's
   // chunks behind them, and only then are the slab's elements awaited and written to LDS.
@@ -385,7 +464,8 @@ __global__ __launch_bounds__(256, PVW_PACKED_WPC) void mac_rows_packedw_kernel(M
     group(g, xa, xb);
     if (g + 1 < gw) group(g + 1, xb, xa);
   }
-  const Mod m = mods[limb];
+  const Mod m = t.mods[limb];
+  if (wave == 0 && it.e_small) add_pf = mac_small_make<ELL>(it, t, m, small, lane, rho, sp, adl);
   v2u64 part;
   part.x = acc_reduce(a0, m);
   part.y = acc_reduce(a1, m);
@@ -642,27 +722,27 @@ hipError_t launch_mac_rows(const MacSection& a, const MacSection& b, const u64* 
     case 16:
 #if PVW_TUNING
       if (variant == 40 && k % 64 == 0) {
-        if (ell == 8) mac_rows_kernel<8, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
-        else mac_rows_kernel<16, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        if (ell == 8) mac_rows_kernel<8, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
+        else mac_rows_kernel<16, 16, true, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
         break;
       }
       if (variant == 17) {
-        if (ell == 8) mac_rows_kernel<8, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
-        else mac_rows_kernel<16, 16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        if (ell == 8) mac_rows_kernel<8, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
+        else mac_rows_kernel<16, 16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
         break;
       }
 #endif
       if (k % 64 == 0) {
-        if (ell == 8) mac_rows_kernel<8, 16, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
-        else mac_rows_kernel<16, 16, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        if (ell == 8) mac_rows_kernel<8, 16, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
+        else mac_rows_kernel<16, 16, true><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
       } else if (ell == 8) {
-        mac_rows_kernel<8, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        mac_rows_kernel<8, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
       } else {
-        mac_rows_kernel<16, 16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        mac_rows_kernel<16, 16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
       }
       break;
-    case 32: mac_rows_kernel<32, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L); break;
-    case 64: mac_rows_kernel<64, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L); break;
+    case 32: mac_rows_kernel<32, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L); break;
+    case 64: mac_rows_kernel<64, 8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -686,19 +766,19 @@ hipError_t launch_mac_rows_packed(const MacSection& a, const MacSection& b, cons
 #define PVW_PACKEDW(Wv)                                                                                   \
   do {                                                                                                    \
     if (stamp) {                                                                                          \
-      if (ell == 8) mac_rows_packedw_kernel<8, Wv, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);   \
-      else mac_rows_packedw_kernel<16, Wv, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);           \
-    } else if (ell == 8) mac_rows_packedw_kernel<8, Wv><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);   \
-    else mac_rows_packedw_kernel<16, Wv><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);                  \
+      if (ell == 8) mac_rows_packedw_kernel<8, Wv, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);   \
+      else mac_rows_packedw_kernel<16, Wv, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);           \
+    } else if (ell == 8) mac_rows_packedw_kernel<8, Wv><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);   \
+    else mac_rows_packedw_kernel<16, Wv><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);                  \
   } while (0)
   const bool stamp = PVW_TUNING && PVW_ENV_INT("PVW_MAC_VARIANT", 0) == 44;   // per-workgroup time stamps (tools/mac_timeline.py c3 44)
   switch (width) {
     case 61:
       if (stamp) {
-        if (ell == 8) mac_rows_packed61_kernel<8, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
-        else mac_rows_packed61_kernel<16, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
-      } else if (ell == 8) mac_rows_packed61_kernel<8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
-      else mac_rows_packed61_kernel<16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t.mods, k, L);
+        if (ell == 8) mac_rows_packed61_kernel<8, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
+        else mac_rows_packed61_kernel<16, PVW_TUNING != 0><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
+      } else if (ell == 8) mac_rows_packed61_kernel<8><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
+      else mac_rows_packed61_kernel<16><<<grid, dim3(256), 0, s>>>(sa, sb, rhat, t, k, L);
       break;
     case 56: PVW_PACKEDW(56); break;
     case 48: PVW_PACKEDW(48); break;

@@ -255,13 +255,13 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
   if (work0) {
     locate(gp0 + p0, ji0, local0);
     m0 = t.mods[limb0];
-    if (jobs[ji0].scalars) scalar0 = jobs[ji0].scalars[(size_t)rep * jobs[ji0].rep_scalars + local0];
+    if (jobs[ji0].scalars && !jobs[ji0].raw_out) scalar0 = jobs[ji0].scalars[(size_t)rep * jobs[ji0].rep_scalars + local0];
   }
   if (tid < PB && tid < 64 && gp0 + tid < b.total) {
     u32 ji, local;
     locate(gp0 + tid, ji, local);
     const PrologueJob& job = jobs[ji];
-    i64* o = sc + tid * ELL;
+    i64* o = job.raw_out ? job.raw_out + (size_t)local * ELL : sc + tid * ELL;    // sampled-only families go straight to memory
     if (job.explicit_coeffs) {
       const i64* ec = job.explicit_coeffs + (size_t)rep * job.rep_coeffs;
 #pragma unroll
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(PrologueBatch b, u32 L, u
       scalar = jobs[ji].scalars ? jobs[ji].scalars[(size_t)rep * jobs[ji].rep_scalars + local] : 0;
     }
     const PrologueJob& job = jobs[ji];
+    if (job.raw_out) continue;                           // nothing to transform
     const u64* tw = stage_tables ? tab + (size_t)limb * ELL : t.tw + (size_t)limb * ELL;
     const u64* twp = stage_tables ? tab + n + (size_t)limb * ELL : t.twp + (size_t)limb * ELL;
     u64 a[ELL];

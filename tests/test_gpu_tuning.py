@@ -33,11 +33,14 @@ def test_tuning_build_is_selected():
 def test_mac_rows_schedules_agree_with_c_oracle(n, k, l, L, monkeypatch):
     # the schedules of the tiled-stream mac_rows that are left (PVW_MAC_VARIANT: 0 by shape -- which streams the packed copy
     # where it can --, 17 not interleaved, 40 interleaved + time stamps): the same c1, c2 (encryption.rs:158,177-200)
+    # each with the addends in compact form (what ships for l <= 16) and as full polynomials from the prologue (PVW_MAC_COMPACT=0)
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for variant in (0, 17, 40):
-        monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
-        ct = run()
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), variant
+    for compact in ("1", "0"):
+        monkeypatch.setenv("PVW_MAC_COMPACT", compact)
+        for variant in (0, 17, 40):
+            monkeypatch.setenv("PVW_MAC_VARIANT", str(variant))
+            ct = run()
+            assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (compact, variant)
 
 
 @pytest.mark.parametrize("n,k,l,L", T.MAC_PACKED_CASES)
@@ -45,11 +48,12 @@ def test_mac_rows_packed_and_unpacked_streams_agree(n, k, l, L, monkeypatch):
     # PVW_MAC_PACKED=0: the geometries the shipped library streams from the 61-bit packed copy, served by the
     # unpacked mac_rows_kernel instead; 44: the stamped packed kernel -- same ciphertexts, all equal to the oracle's
     run, c1o, c2o = T.mac_rows_case(n, k, l, L)
-    for packed, variant, width in (("1", "0", 61), ("0", "0", 0), ("1", "44", 61)):
+    for packed, variant, compact, width in (("1", "0", "1", 61), ("0", "0", "1", 0), ("1", "44", "1", 61), ("1", "0", "0", 61), ("0", "0", "0", 0)):
         monkeypatch.setenv("PVW_MAC_PACKED", packed)
         monkeypatch.setenv("PVW_MAC_VARIANT", variant)
+        monkeypatch.setenv("PVW_MAC_COMPACT", compact)
         ct = run()
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (packed, variant)
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (packed, variant, compact)
         if packed == "1":
             assert run.params.packed_active() == width
 
@@ -58,11 +62,12 @@ def test_mac_rows_packed_and_unpacked_streams_agree(n, k, l, L, monkeypatch):
 def test_mac_rows_width_streams_stamped_and_unpacked(n, k, l, moduli, width, monkeypatch):
     # the 40 / 48 / 56-bit streams with per-workgroup time stamps (44), and the same geometry from the tiled matrices
     run, c1o, c2o = T.mac_rows_case(n, k, l, None, moduli)
-    for packed, variant in (("1", "44"), ("0", "0"), ("1", "0")):
+    for packed, variant, compact in (("1", "44", "1"), ("0", "0", "1"), ("1", "0", "0"), ("1", "0", "1")):
         monkeypatch.setenv("PVW_MAC_PACKED", packed)
         monkeypatch.setenv("PVW_MAC_VARIANT", variant)
+        monkeypatch.setenv("PVW_MAC_COMPACT", compact)
         ct = run()
-        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (packed, variant)
+        assert np.array_equal(ct.c1, c1o) and np.array_equal(ct.c2, c2o), (packed, variant, compact)
     assert run.params.packed_active() == width
 
 
@@ -133,7 +138,7 @@ def test_switches_exist_only_in_the_tuning_build(monkeypatch):
         return ct.c1.copy(), ct.c2.copy(), p.packed_active()
     want = once("default")
     assert want[2] == 61 and once("tuning")[2] == 61
-    for name, val in (("PVW_MAC_PACKED", "0"), ("PVW_DECODE_TIMING", "1"), ("PVW_GEMM_ZERO_OPERANDS", "1"), ("PVW_MAC_VARIANT", "17")):
+    for name, val in (("PVW_MAC_PACKED", "0"), ("PVW_MAC_COMPACT", "0"), ("PVW_DECODE_TIMING", "1"), ("PVW_GEMM_ZERO_OPERANDS", "1"), ("PVW_MAC_VARIANT", "17")):
         monkeypatch.setenv(name, val)
     got = once("default")
     assert all(np.array_equal(a, b) for a, b in zip(got[:2], want[:2])) and got[2] == 61, "the shipped library reacted to a tuning variable"
