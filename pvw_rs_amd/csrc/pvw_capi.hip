@@ -265,6 +265,13 @@ static void build_tables(pvw_ctx* c) {
   }
 }
 
+static double correctness_bound(double n, double k, double l, double b1, double b2) {  // parameters.rs:510-544
+  double first = b2 * std::sqrt(n * l) * (1.0 + std::sqrt(n));
+  double second = 2.0 * b1 * k * l;
+  double third = 14.0 * b1 * std::sqrt(n * k * l);
+  return first + second + third;
+}
+
 // ---- decode tables (pvw_decode.h): big constants as W little-endian words ----
 static void bn_words(const BigInt& v, size_t W, u64* out) {
   for (size_t i = 0; i < W; ++i) out[i] = i < v.mag.size() ? v.mag[i] : 0;
@@ -274,14 +281,14 @@ static void build_decode_tables(pvw_ctx* c) {
   const size_t W = (c->Q.bits() + 8 + 63) / 64;
   // layout (u64 words): Q | halfQ | qi[L][W] | inv[L] | invp[L] | pow64[L][W] | dmod[L] | dmodp[L] |
   //                     delta | dpow | half_dpow | dpow_n | td_n
-  const size_t total = 2 * W + L * W + 2 * L + L * W + 2 * L + 5 * W + W * L + 3 * (W + 2);
+  const size_t total = 2 * W + L * W + 2 * L + L * W + 2 * L + 5 * W + W * L + 3 * (W + 2) + 56 + 9;
   c->dec_words.assign(total, 0);
   u64* p = c->dec_words.data();
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += n; return o; };
   const size_t oQ = take(W), oH = take(W), oQi = take(L * W), oInv = take(L), oInvp = take(L), oPow = take(L * W),
                oDm = take(L), oDmp = take(L), oDelta = take(W), oDpow = take(W), oHalfD = take(W), oDpn = take(W), oTdn = take(W),
-               oPowT = take(W * L), oTd = take(W + 2), oMuTd = take(W + 2), oMuDp = take(W + 2);
+               oPowT = take(W * L), oTd = take(W + 2), oMuTd = take(W + 2), oMuDp = take(W + 2), oGar = take(56), oSc = take(9);
   bn_words(c->Q, W, p + oQ);
   bn_words(c->halfQ, W, p + oH);
   for (size_t i = 0; i < L; ++i) {
@@ -315,13 +322,60 @@ static void build_decode_tables(pvw_ctx* c) {
   t.W = (u32)W; t.L = c->L; t.ell = c->l;
   norm(c->delta_pow, p + oDpn, t.dpow_nw, t.dpow_sh);
   norm(c->delta * BigInt(2), p + oTdn, t.td_nw, t.td_sh);
+  // Garner constants of the short-cut lift (pvw_decode_wave.h).  A well-formed ciphertext's chain inputs are at most about
+  // Delta times the decryption noise; the noise is below the bound of the correctness gate (parameters.rs:510-544).  Use as
+  // many of the leading moduli as make half their product cover that with a few bits to spare: at least 2, at most 4, and
+  // at least one limb must remain to confirm a candidate against.  (Whatever does not fit takes the full lift: the choice
+  // only decides how often the short cut applies.)
+  t.gar_n = 0;
+  if (L >= 3) {
+    const double bound = correctness_bound((double)c->n, (double)c->k, (double)c->l, (double)c->b1, (double)c->b2);
+    const size_t need = c->delta.bits() + (size_t)std::ceil(std::log2(bound + 2.0)) + 4;
+    const size_t most = std::min<size_t>(4, L - 1);
+    u64* g = p + oGar;
+    BigInt prod(1);
+    size_t nl = 0;
+    while (nl < most && (nl < 2 || prod.bits() < need + 1)) prod = prod * BigInt(c->moduli[nl++]);
+    t.gar_n = (u32)nl;
+    t.gar_close = 1;
+    prod = BigInt(1);
+    for (size_t j = 0; j <= nl; ++j) {
+      bn_words(prod, 4, g + 32 + 4 * j);
+      if (j == nl) break;
+      for (size_t i = 0; i < j; ++i) {
+        const u64 v = powmod(c->moduli[i] % c->moduli[j], c->moduli[j] - 2, c->mods[j]);
+        g[4 * j + i] = v;
+        g[16 + 4 * j + i] = shoup_precompute(v, c->moduli[j]);
+        if (c->moduli[i] >= 2 * c->moduli[j]) t.gar_close = 0;
+      }
+      prod = prod * BigInt(c->moduli[j]);
+    }
+    bn_words(prod.shr(1), 4, g + 52);
+  }
+  // constants of the chain step on noise-sized operands: an operand below 2^191 on either side keeps a - b inside
+  // (-Q/2, Q/2) once Q has 194 bits, so the integer difference IS the centred difference the reference takes mod Q
+  {
+    const BigInt td = c->delta * BigInt(2);
+    t.sc_on = (t.gar_n != 0 && c->Q.bits() >= 194 && td.mag.size() <= 3) ? 1 : 0;
+    if (t.sc_on) {
+      u64* sc = p + oSc;
+      const size_t sh = 192 - td.bits();
+      const BigInt td3 = td.shl(sh);
+      bn_words(td3, 3, sc);
+      const BigInt recip = (BigInt(1).shl(128) - BigInt(1)) / BigInt(sc[2]) - BigInt(1).shl(64);
+      bn_words(recip, 1, sc + 3);
+      sc[4] = sh / 64;
+      sc[5] = sh % 64;
+      bn_words(c->delta, 3, sc + 6);
+    }
+  }
   auto bind = [&](DecodeTables& d, const u64* base, const Mod* mods) {
     d = t;
     d.mods = mods;
     d.Q = base + oQ; d.halfQ = base + oH; d.qi = base + oQi; d.inv = base + oInv; d.invp = base + oInvp;
     d.pow64 = base + oPow; d.dmod = base + oDm; d.dmodp = base + oDmp; d.delta = base + oDelta;
     d.dpow = base + oDpow; d.half_dpow = base + oHalfD; d.dpow_n = base + oDpn; d.td_n = base + oTdn;
-    d.pow64T = base + oPowT; d.td = base + oTd; d.mu_td = base + oMuTd; d.mu_dp = base + oMuDp;
+    d.pow64T = base + oPowT; d.td = base + oTd; d.mu_td = base + oMuTd; d.mu_dp = base + oMuDp; d.gar = base + oGar; d.sc = base + oSc;
   };
   bind(c->dec_host, p, c->mods.data());
   c->dec_dev = t;   // pointers bound at upload
@@ -377,7 +431,7 @@ static int32_t upload_tables(pvw_ctx* c) {
     d.Q = mv(d.Q); d.halfQ = mv(d.halfQ); d.qi = mv(d.qi); d.inv = mv(d.inv); d.invp = mv(d.invp); d.pow64 = mv(d.pow64);
     d.dmod = mv(d.dmod); d.dmodp = mv(d.dmodp); d.delta = mv(d.delta); d.dpow = mv(d.dpow); d.half_dpow = mv(d.half_dpow);
     d.dpow_n = mv(d.dpow_n); d.td_n = mv(d.td_n);
-    d.pow64T = mv(d.pow64T); d.td = mv(d.td); d.mu_td = mv(d.mu_td); d.mu_dp = mv(d.mu_dp);
+    d.pow64T = mv(d.pow64T); d.td = mv(d.td); d.mu_td = mv(d.mu_td); d.mu_dp = mv(d.mu_dp); d.gar = mv(d.gar); d.sc = mv(d.sc);
     c->dec_dev = d;
   }
   PVW_HIP(hipDeviceSynchronize());
@@ -540,12 +594,6 @@ static void compute_q_delta(const u64* moduli, u32 L, u32 l, BigInt& Q, BigInt& 
   dpow = delta.pow(l - 1);          // :159-163
 }
 
-static double correctness_bound(double n, double k, double l, double b1, double b2) {  // parameters.rs:510-544
-  double first = b2 * std::sqrt(n * l) * (1.0 + std::sqrt(n));
-  double second = 2.0 * b1 * k * l;
-  double third = 14.0 * b1 * std::sqrt(n * k * l);
-  return first + second + third;
-}
 
 extern "C" {
 

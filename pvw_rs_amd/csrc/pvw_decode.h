@@ -48,6 +48,17 @@ struct DecodeTables {
   const u64* td;      // [W+2]  2*Delta
   const u64* mu_td;   // [W+2]
   const u64* mu_dp;   // [W+2]
+  // short-cut lift of small values (pvw_decode_wave.h: wave_lift_small): Garner constants over the first gar_n <= 4 moduli
+  // (0 = not used).  inv[j][i] = q_i^-1 mod q_j (i < j) at [4 j + i] | their Shoup companions at [16 + 4 j + i] |
+  // prod[j] = q_0 .. q_{j-1} as 4 words at [32 + 4 j], j = 0..4 | floor(prod[gar_n] / 2) at [52]
+  u32 gar_n;
+  u32 gar_close;      // q_i < 2 q_j for all i < j < gar_n: a mixed-radix digit reduces to the next modulus with one subtraction
+  const u64* gar;     // [56]
+  // chain steps on noise-sized operands (pvw_decode_wave.h: small_chain_step), used when sc_on: Q has at least 194 bits
+  // and 2*Delta at most three words.  [0..2] 2*Delta shifted left until bit 191 is set | [3] Moeller-Granlund reciprocal
+  // of its top word, floor((2^128 - 1) / d2) - 2^64 | [4] whole words of that shift | [5] bits of it | [6..8] Delta
+  u32 sc_on;
+  const u64* sc;      // [9]
 };
 
 PVW_HD void bn_zero(BN a, int W) { for (int i = 0; i < W; ++i) a[i] = 0; }

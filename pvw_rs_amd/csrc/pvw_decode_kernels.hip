@@ -51,7 +51,7 @@ hipError_t init_kernel_attributes() {
 
 // LDS bytes of decode_chain_kernel for cpw ciphertexts of wpc waves per workgroup
 static size_t decode_chain_lds(const DecodeTables& t, u32 cpw, u32 wpc) {
-  return ((size_t)t.L * t.W + 2 * (2 * t.W + 2) + (size_t)cpw * ((size_t)(t.ell + 1) * 64 + (size_t)t.L * t.ell) + (size_t)cpw * wpc * 64) * 8;
+  return ((size_t)t.L * t.W + 2 * (2 * t.W + 2) + 256 + (size_t)cpw * ((size_t)(t.ell + 1) * 64 + (size_t)t.L * t.ell + (size_t)5 * t.ell + 2)) * 8;
 }
 
 hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s) {
@@ -67,7 +67,8 @@ hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeT
       const dim3 grid((u32)((count + cpw - 1) / cpw)), block(cpw * wpc * 64);
       // tuning build only: PVW_DECODE_TIMING=1..6: out[] = cycles of a phase (results are NOT values; tools/decode_timing.py)
       const u32 dbg = (u32)PVW_ENV_INT("PVW_DECODE_TIMING", 0);
-      decode_chain_kernel<<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | (dbg << 16), t);
+      const u32 no_small = PVW_ENV_INT("PVW_DECODE_SMALL", 1) == 0 ? 1u << 31 : 0;     // tuning build: every lift in full
+      decode_chain_kernel<<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | ((dbg & 0xff) << 16) | no_small, t);
       return hipGetLastError();
     }
   }

@@ -110,8 +110,7 @@ __device__ __forceinline__ void mac_loop4(Acc& acc, u32 n, LoadF ld, ScalF sc) {
 struct WaveDecodeCtx {
   const DecodeTables& t;
   const u64* qiL;    // LDS copy of t.qi    [L][W]
-  const u64* powL;   // LDS copy of t.pow64T [W][L]
-  u64* xs;     // per-wave LDS scratch, 64 words
+  const u64* powL;   // LDS copy of the first four rows of t.pow64T, [4][64]: 2^(64 w) mod q_lane
   u32 lane;
   u32 W, L;
   Mod m;       // this lane's limb modulus (lanes >= L: limb 0, masked out by `limb_on`)
@@ -162,6 +161,223 @@ __device__ __forceinline__ u64 wave_lift_centered(const WaveDecodeCtx& c, u64 re
   }
   return x;
 }
+// The same lift for values that are SMALL against Q.  For a well-formed ciphertext the chain inputs tmp_i = z_i*Delta -
+// z_{i+1} and z_0 are noise-sized (a few words: noise times Delta) while Q has W words, and the full lift above spends
+// L broadcast steps and a W-word reduction on each.  A value whose centred representative v satisfies |v| <= P/2,
+// P = q_0..q_{n-1} the product of the first n = gar_n <= 4 moduli, is determined by its first n residues alone:
+//   small_candidates  one lane per chain input of this wave: Garner's mixed-radix digits from the n residues, v centred
+//                     modulo P as four words + sign, parked in the wave's LDS scratch (five words per input)
+//   small_confirm     per input, one limb per lane: |v| mod q_limb from the power rows, sign applied, must equal the
+//                     residue on EVERY limb -- then v = x mod Q centred (|v| <= P/2 < Q/2, the representative is
+//                     unique) and x in [0, Q) is returned one word per lane; otherwise false, nothing assumed, and the
+//                     caller takes the full lift.  Results are identical either way.
+__device__ __forceinline__ void small_candidates(const WaveDecodeCtx& c, const u64* zs, u32 l, u32 item, u64* park) {
+  const DecodeTables& t = c.t;
+  const u32 NL = t.gar_n;
+  const u64* g = t.gar;
+  u64 xm[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (u32 j = 0; j < 4; ++j) {
+    if (j < NL) {
+      const Mod mj = t.mods[j];
+      const u64* z = zs + (size_t)j * l;
+      // this input's residue at limb j: tmp_item (decryption.rs:19-27) or z_0 (item == l)
+      u64 u = item < l ? submod(mulmod_shoup(z[item], t.dmod[j], t.dmodp[j], mj.q), z[item + 1], mj.q) : z[0];
+#pragma unroll
+      for (u32 i = 0; i < j; ++i) {
+        u = submod(u, t.gar_close ? (xm[i] >= mj.q ? xm[i] - mj.q : xm[i]) : reduce128(xm[i], 0, mj), mj.q);
+        u = mulmod_shoup(u, g[4 * j + i], g[16 + 4 * j + i], mj.q);
+      }
+      xm[j] = u;
+    }
+  }
+  // v = x_0 + x_1 q_0 + x_2 q_0 q_1 + x_3 q_0 q_1 q_2  < P
+  u64 v0, v1, v2 = 0, v3 = 0;
+  {
+    u128 p = (u128)xm[1] * g[36] + xm[0];
+    v0 = (u64)p;
+    v1 = (u64)(p >> 64);
+  }
+  if (NL > 2) {
+    u128 p = (u128)xm[2] * g[40] + v0;
+    v0 = (u64)p;
+    p = (u128)xm[2] * g[41] + v1 + (u64)(p >> 64);
+    v1 = (u64)p;
+    v2 = (u64)(p >> 64);
+  }
+  if (NL > 3) {
+    u128 p = (u128)xm[3] * g[44] + v0;
+    v0 = (u64)p;
+    p = (u128)xm[3] * g[45] + v1 + (u64)(p >> 64);
+    v1 = (u64)p;
+    p = (u128)xm[3] * g[46] + v2 + (u64)(p >> 64);
+    v2 = (u64)p;
+    v3 = (u64)(p >> 64);
+  }
+  // centre modulo P
+  const u128 vlo = ((u128)v1 << 64) | v0, vhi = ((u128)v3 << 64) | v2;
+  const u128 hlo = ((u128)g[53] << 64) | g[52], hhi = ((u128)g[55] << 64) | g[54];
+  const bool ng = vhi != hhi ? vhi > hhi : vlo > hlo;
+  if (ng) {
+    const u64* P = g + 32 + 4 * NL;
+    const u128 plo = ((u128)P[1] << 64) | P[0], phi = ((u128)P[3] << 64) | P[2];
+    const u128 dlo = plo - vlo, dhi = phi - vhi - (plo < vlo ? 1 : 0);
+    v0 = (u64)dlo; v1 = (u64)(dlo >> 64); v2 = (u64)dhi; v3 = (u64)(dhi >> 64);
+  }
+  park[0] = v0; park[1] = v1; park[2] = v2; park[3] = v3; park[4] = ng ? 1 : 0;
+}
+__device__ __forceinline__ bool small_confirm(const WaveDecodeCtx& c, u64 res, u64* park, u64& x) {
+  const u32 lane = c.lane;
+  const u64 v0 = park[0], v1 = park[1], v2 = park[2], v3 = park[3];
+  const bool ng = park[4] != 0;
+  const u64* pw = c.powL + (c.limb_on ? lane : 0);
+  u128 sum = (u128)v0 * pw[0] + (u128)v1 * pw[64];        // at most four terms < 2^126 each (q < 2^62)
+  if (v2) sum += (u128)v2 * pw[128];
+  if (v3) sum += (u128)v3 * pw[192];
+  u64 sres = reduce128((u64)sum, (u64)(sum >> 64), c.m);
+  if (ng && sres) sres = c.m.q - sres;
+  if (__ballot(c.limb_on && sres != res)) return false;
+  if (lane == 0) park[4] = (ng ? 1 : 0) | 2;               // confirmed: the chain may use the signed magnitude as it stands
+  x = lane == 0 ? v0 : (lane == 1 ? v1 : (lane == 2 ? v2 : (lane == 3 ? v3 : 0)));
+  if (ng) x = wave_sub(c.Qw, x, lane);                     // the representative in [0, Q)
+  return true;
+}
+
+// One step of the chain, noise_i = round((noise_{i+1} - tmp_i) / Delta) (decryption.rs:44-48, :180-207), on noise-sized
+// operands held by ONE LANE: noise_{i+1} = a and tmp_i = the confirmed candidate cb, both below 2^191 in magnitude, so
+// the step is a few dozen word operations (the general step below spends ~20 ballots and lane shifts on W-word integers
+// that are almost all zeros).  With Q >= 2^193 the integer a - b is the centred difference mod Q; round(p / Delta) =
+// sign(p) * floor((2|p| + Delta) / (2 Delta)) as the general step computes it, here by one Knuth step (4 words by 3,
+// one-word quotient, trial digit from the top words by Moeller-Granlund's reciprocal).  Returns false when an operand or
+// the quotient does not fit (q, qneg are then meaningless).
+struct SmallVal {
+  u64 w0, w1, w2;
+  bool neg;
+};
+__device__ __forceinline__ bool small_chain_step(const u64* sc, const SmallVal& a, const u64* cb, u64& q, bool& qneg) {
+  const u64 b0 = cb[0], b1 = cb[1], b2 = cb[2], b3 = cb[3], bf = cb[4];
+  bool ok = (bf & 2) != 0 && b3 == 0 && (b2 >> 63) == 0 && (a.w2 >> 63) == 0;
+  const bool bneg = (bf & 1) != 0;
+  u64 p0, p1, p2, p3;                                      // |p|, p = a - b
+  bool pneg;
+  if (a.neg != bneg) {
+    u128 s = (u128)a.w0 + b0;
+    p0 = (u64)s;
+    s = (u128)a.w1 + b1 + (u64)(s >> 64);
+    p1 = (u64)s;
+    s = (u128)a.w2 + b2 + (u64)(s >> 64);
+    p2 = (u64)s;
+    p3 = (u64)(s >> 64);
+    pneg = a.neg;
+  } else {
+    const bool age = a.w2 != b2 ? a.w2 > b2 : (a.w1 != b1 ? a.w1 > b1 : a.w0 >= b0);
+    const u64 x0 = age ? a.w0 : b0, x1 = age ? a.w1 : b1, x2 = age ? a.w2 : b2;
+    const u64 y0 = age ? b0 : a.w0, y1 = age ? b1 : a.w1, y2 = age ? b2 : a.w2;
+    const u128 xl = ((u128)x1 << 64) | x0, yl = ((u128)y1 << 64) | y0, dl = xl - yl;
+    p0 = (u64)dl;
+    p1 = (u64)(dl >> 64);
+    p2 = x2 - y2 - (xl < yl ? 1 : 0);
+    p3 = 0;
+    pneg = age ? a.neg : !a.neg;
+  }
+  // 2|p| + Delta
+  u64 n0 = p0 << 1, n1 = (p1 << 1) | (p0 >> 63), n2 = (p2 << 1) | (p1 >> 63), n3 = (p3 << 1) | (p2 >> 63);
+  {
+    u128 s = (u128)n0 + sc[6];
+    n0 = (u64)s;
+    s = (u128)n1 + sc[7] + (u64)(s >> 64);
+    n1 = (u64)s;
+    s = (u128)n2 + sc[8] + (u64)(s >> 64);
+    n2 = (u64)s;
+    n3 += (u64)(s >> 64);
+  }
+  // the shift that normalised the divisor; anything pushed out means a quotient of more than one word
+  const u32 ws = (u32)sc[4], bs = (u32)sc[5];              // wave-uniform
+  u64 m0, m1, m2, m3;
+  if (ws == 0) {
+    m0 = n0; m1 = n1; m2 = n2; m3 = n3;
+  } else if (ws == 1) {
+    ok = ok && n3 == 0;
+    m0 = 0; m1 = n0; m2 = n1; m3 = n2;
+  } else {
+    ok = ok && (n3 | n2) == 0;
+    m0 = 0; m1 = 0; m2 = n0; m3 = n1;
+  }
+  if (bs) {
+    ok = ok && (m3 >> (64 - bs)) == 0;
+    m3 = (m3 << bs) | (m2 >> (64 - bs));
+    m2 = (m2 << bs) | (m1 >> (64 - bs));
+    m1 = (m1 << bs) | (m0 >> (64 - bs));
+    m0 <<= bs;
+  }
+  const u64 d0 = sc[0], d1 = sc[1], d2 = sc[2], v = sc[3];
+  ok = ok && (m3 != d2 ? m3 < d2 : (m2 != d1 ? m2 < d1 : m1 < d0));              // one-word quotient
+  u64 qh = ~0ULL;                                          // trial digit, at most 2 too large (Knuth D3)
+  if (m3 < d2) {
+    const u128 qq = (u128)v * m3 + (((u128)m3 << 64) | m2);
+    u64 q1 = (u64)(qq >> 64) + 1;
+    const u64 q0 = (u64)qq;
+    u64 r = m2 - q1 * d2;
+    if (r > q0) { --q1; r += d2; }
+    if (r >= d2) { ++q1; r -= d2; }
+    qh = q1;
+  }
+  // m - qh * d; below zero: the trial was too large
+  const u128 t0 = (u128)qh * d0, t1 = (u128)qh * d1 + (u64)(t0 >> 64), t2 = (u128)qh * d2 + (u64)(t1 >> 64);
+  const u128 ml = ((u128)m1 << 64) | m0, mh = ((u128)m3 << 64) | m2;
+  const u128 tl = ((u128)(u64)t1 << 64) | (u64)t0;
+  u128 rl = ml - tl;
+  const u128 th_b = t2 + (ml < tl ? 1 : 0);                // t2 <= 2^128 - 2^64: the borrow cannot wrap it
+  bool below = ok && mh < th_b;
+  u128 rh = mh - th_b;
+  const u128 dlw = ((u128)d1 << 64) | d0;
+  for (int fix = 0; fix < 2 && below; ++fix) {
+    --qh;
+    const u128 nl = rl + dlw;
+    const u128 nh = rh + d2 + (nl < rl ? 1 : 0);
+    below = nh >= rh;                                      // no wrap past 2^128: still below zero (d2 + carry > 0)
+    rl = nl;
+    rh = nh;
+  }
+  q = qh;
+  qneg = pneg && qh != 0;
+  return ok && !below;
+}
+// The whole chain for noise-sized values.  The steps are serial by definition -- noise_i needs noise_{i+1} -- but for
+// a well-formed ciphertext noise_{i+1} is ~2^-100 of tmp_i and moves round((noise_{i+1} - tmp_i)/Delta) only on a
+// rounding boundary.  So lane i takes step i with a guess for its input (first pass: 0; later passes: what the lane
+// above produced in the pass before; the top lane always has the true noise_{l-1}), all lanes at once, until a pass
+// reproduces the one before.  That fixed point IS the chain: the top lane's input is exact, hence its output, hence the
+// input the next lane used in the confirming pass, and so on down.  false (nothing assumed) when a step does not fit the
+// short form or the passes do not settle in `max_pass`; the caller then walks the chain step by step.
+__device__ __forceinline__ bool small_chain(const u64* sc, const u64* cand, u32 l, u32 lane, const SmallVal& top, SmallVal& out) {
+  const bool mine = lane + 1 < l;                          // steps 0 .. l-2
+  const u64* cb = cand + (size_t)(mine ? lane : 0) * 5;
+  u64 q = 0;
+  bool qneg = false;
+  const int max_pass = 4;
+  for (int pass = 0; pass < max_pass; ++pass) {
+    SmallVal a;
+    a.w0 = lane_down1_u64(q);                              // lane i <- lane i+1
+    a.w1 = a.w2 = 0;
+    a.neg = lane_down1((u32)qneg) != 0;
+    if (lane + 2 == l) a = top;
+    u64 nq;
+    bool nneg;
+    const bool ok = small_chain_step(sc, a, cb, nq, nneg);
+    if (__ballot(mine && !ok)) return false;
+    const bool same = nq == q && nneg == qneg;
+    q = nq;
+    qneg = nneg;
+    if (pass > 0 && __ballot(mine && !same) == 0) {
+      out.w0 = readlane_u64(q, 0);
+      out.w1 = out.w2 = 0;
+      out.neg = __builtin_amdgcn_readlane((int)qneg, 0) != 0;
+      return true;
+    }
+  }
+  return false;
+}
 // floor(N / d) and N mod d via the reciprocal mu = floor(B^(W+1)/d): N and d (one word per lane, dw; dn = its
 // significant words) are read lane-to-lane (v_readlane); only the reciprocal is a table, W+2 words zero-padded to
 // 2W+2 so that the column loop has no bounds test.  N < B^W.  Returns quotient in q, remainder in r.
@@ -173,7 +389,10 @@ __device__ __forceinline__ void wave_divmod2(const WaveDecodeCtx& c, u64 n, cons
   u64 c0, c1, c2;
   Acc acc;
   acc_zero(acc);
-  mac_loop4(acc, W, [&](u32 i) { return *(mp - i); }, [&](u32 i) { return readlane_u64(n, i); });
+  // only N's significant words contribute: the chain's numerators are a few words long for a well-formed ciphertext
+  const unsigned long long nzw = __ballot(n != 0);
+  const u32 ns = nzw ? 64 - (u32)__builtin_clzll(nzw) : 0;
+  mac_loop4(acc, ns, [&](u32 i) { return *(mp - i); }, [&](u32 i) { return readlane_u64(n, i); });
   acc_words(acc, c0, c1, c2);
   u64 p = wave_normalize(c0, c1, c2, lane);
   {
@@ -215,54 +434,96 @@ template <int WPC>
 __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy, u64* __restrict__ out,
                                                   u32 count, u32 cpw_dbg, const DecodeTables& t, u32 blk, u64* dws) {
   const u32 cpw = cpw_dbg & 0xffff;
-  const u32 dbg = PVW_TUNING ? (cpw_dbg >> 16) : 0;        // tuning build, dbg != 0: timing experiment, out[] = cycle counts
+  const u32 dbg = PVW_TUNING ? ((cpw_dbg >> 16) & 0xff) : 0;
+  const bool no_small = PVW_TUNING && (cpw_dbg >> 31);     // tuning build: PVW_DECODE_SMALL=0, every lift in full        // tuning build, dbg != 0: timing experiment, out[] = cycle counts
   const u64 tk0 = dbg ? clock64() : 0;
-  // LDS: CRT table [L][W] | two reciprocals, 2W+2 words each | per ciphertext: lifts [l+1][64] + signs, residues [L][l]
-  //      | per wave: 64-word scratch
+  // LDS: CRT table [L][W] | two reciprocals, 2W+2 words each | power rows [4][64] | per ciphertext: lifts [l+1][64] + signs,
+  //      residues [L][l], short-cut candidates [l][5] + the work counter
   const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const u32 W = t.W, L = t.L, l = t.ell;
   const u32 nw = cpw * WPC;
   u64* qiL = dws;
   u64* smallL = dws + (size_t)L * W;                     // mu_dp | mu_td, W+2 words each, zero-padded to 2W+2
-  u64* ctbase = smallL + (size_t)2 * (2 * W + 2);
-  const size_t ct_words = (size_t)(l + 1) * 64 + (size_t)L * l;
+  u64* gpowL = smallL + (size_t)2 * (2 * W + 2);         // 2^(64 w) mod q_lane, w < 4
+  u64* ctbase = gpowL + 256;
+  const size_t ct_words = (size_t)(l + 1) * 64 + (size_t)L * l + (size_t)5 * l + 2;
   const u32 cw = wave / WPC, wsub = wave % WPC;          // ciphertext within the workgroup, wave within it
   u64* Tl = ctbase + (size_t)cw * ct_words;              // [l+1][64]
   u64* zs = Tl + (size_t)(l + 1) * 64;                   // [L][l]
-  u64* xs = ctbase + (size_t)cpw * ct_words + (size_t)wave * 64;
+  u64* cand = zs + (size_t)L * l;                        // [l][5]: four words + sign per chain input
+  u32* next_input = reinterpret_cast<u32*>(cand + (size_t)5 * l);
   for (u32 x = threadIdx.x; x < L * W; x += nw * 64) qiL[x] = t.qi[x];
   for (u32 x = threadIdx.x; x < 2 * W + 2; x += nw * 64) {
     smallL[x] = x < W + 2 ? t.mu_dp[x] : 0;
     smallL[(2 * W + 2) + x] = x < W + 2 ? t.mu_td[x] : 0;
   }
+  for (u32 x = threadIdx.x; x < 256; x += nw * 64) gpowL[x] = ((x & 63) < L && (x >> 6) < W) ? t.pow64T[(size_t)(x >> 6) * L + (x & 63)] : 0;
   const u32 d = blk * cpw + cw;
   const bool live = d < count;                           // uniform over the ciphertext's waves
   if (live)
     for (u32 x = wsub * 64 + lane; x < L * l; x += WPC * 64) zs[x] = noisy[(size_t)d * L * l + x];
   __syncthreads();
-  WaveDecodeCtx c{t, qiL, nullptr, xs, lane, W, L, t.mods[lane < L ? lane : 0], lane < L, lane < W,
+  const u64 tk0b = dbg ? clock64() : 0;
+  WaveDecodeCtx c{t, qiL, gpowL, lane, W, L, t.mods[lane < L ? lane : 0], lane < L, lane < W,
                   lane < W ? t.Q[lane] : 0, lane < W ? t.halfQ[lane] : 0};
   const u64* z = zs + (size_t)(c.limb_on ? lane : 0) * l;
   const u64 dm = t.dmod[c.limb_on ? lane : 0], dmp = t.dmodp[c.limb_on ? lane : 0];
   const u64 q = c.m.q;
   auto tmp = [&](u32 i) -> u64 { return submod(mulmod_shoup(z[i], dm, dmp, q), z[i + 1], q); };   // :19-27
   // ---- phase 1: the l+1 lifts, item = 0..l-2: tmp_i in [0,Q); l-1: Horner value, centred; l: z_0 in [0,Q)
+  // The l chain inputs (tmp_0..tmp_{l-2} and z_0) are noise-sized for a well-formed ciphertext: the ciphertext's first
+  // wave works out a short-cut candidate for each, one lane per input; after a barrier the waves draw inputs from a
+  // counter -- confirm the candidate or lift in full -- the last wave joining once it has lifted the Horner value (always
+  // in full: it is of the order of Delta^(l-1)).
   bool hneg = false;
+  const bool small_on = t.gar_n != 0 && !no_small;
   if (live) {
-    for (u32 item = wsub; item <= l; item += WPC) {
-      bool ng = false;
-      u64 x;
-      if (item + 1 < l) {
-        x = wave_lift_centered<false>(c, tmp(item), ng);
-      } else if (item == l - 1) {
-        u64 h = tmp(0);                                  // Horner over tmp_0 .. tmp_{l-2} (:30-33)
-        for (u32 i = 1; i + 1 < l; ++i) h = addmod(mulmod_shoup(h, dm, dmp, q), tmp(i), q);
-        x = wave_lift_centered<true>(c, h, ng);
-        if (lane == 0) Tl[(size_t)(l - 1) * 64 + 63] = ng ? 1 : 0;    // word 63 is never a value word (W + 2 <= 64)
-      } else {
-        x = wave_lift_centered<false>(c, z[0], ng);
+    if (wsub == 0) {
+      const u64 tc0 = dbg == 9 ? clock64() : 0;
+      if (lane == 0) *next_input = 0;
+      if (small_on && lane < l) small_candidates(c, zs, l, lane + 1 < l ? lane : l, cand + (size_t)lane * 5);
+      if (dbg == 9) {                                    // timing experiment: the candidates
+        const u64 tc1 = clock64();
+        if (lane == 0) out[d] = tc1 - tc0;
       }
-      if (lane < 63 || item != l - 1) Tl[(size_t)item * 64 + lane] = (lane < W) ? x : 0;
+    }
+  }
+  __syncthreads();
+  if (live) {
+    if (wsub == WPC - 1) {
+      const u64 tl0 = dbg == 10 ? clock64() : 0;
+      bool ng = false;
+      u64 h = tmp(0);                                    // Horner over tmp_0 .. tmp_{l-2} (:30-33)
+      for (u32 i = 1; i + 1 < l; ++i) h = addmod(mulmod_shoup(h, dm, dmp, q), tmp(i), q);
+      const u64 x = wave_lift_centered<true>(c, h, ng);
+      if (lane == 0) Tl[(size_t)(l - 1) * 64 + 63] = ng ? 1 : 0;      // word 63 is never a value word (W + 2 <= 64)
+      if (lane < 63) Tl[(size_t)(l - 1) * 64 + lane] = (lane < W) ? x : 0;
+      if (dbg == 10) {                                   // timing experiment: Horner value and its full lift
+        const u64 tl1 = clock64();
+        if (lane == 0) out[d] = tl1 - tl0;
+      }
+    }
+    bool try_small = small_on;
+    for (bool first = true;; first = false) {
+      u32 idx = 0;
+      if (lane == 0) idx = atomicAdd(next_input, 1u);
+      idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
+      if (idx >= l) break;
+      const u32 item = idx + 1 < l ? idx : l;            // slot l-1 of the lifts is the Horner value's
+      const u64 tl0 = dbg == 8 ? clock64() : 0;
+      const u64 res = item < l ? tmp(item) : z[0];
+      bool done = false, ng = false;
+      u64 x;
+      if (try_small) {
+        done = small_confirm(c, res, cand + (size_t)idx * 5, x);
+        try_small = done;                                // one refusal: the rest of this wave's inputs go the long way
+      }
+      if (!done) x = wave_lift_centered<false>(c, res, ng);
+      Tl[(size_t)item * 64 + lane] = (lane < W) ? x : 0;
+      if (dbg == 8 && first && wsub == 0) {              // timing experiment: the first input the first wave settles
+        const u64 tl1 = clock64();
+        if (lane == 0) out[d] = tl1 - tl0;
+      }
     }
   }
   __syncthreads();
@@ -299,18 +560,28 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
     }
     return v;
   };
-  // noise_i = round((noise_{i+1} - tmp_i) / Delta), i = l-2 .. 0   (:44-48, :180-207)
-  for (u32 i = l - 1; i-- > 0;) {
+  // noise_i = round((noise_{i+1} - tmp_i) / Delta), i = l-2 .. 0   (:44-48, :180-207): all steps at once while the values
+  // are noise-sized (small_chain), else step by step, one word per lane
+  bool chain_done = false;
+  if (small_on && t.sc_on && l >= 2 && __ballot(lane >= 3 && nm != 0) == 0) {
+    SmallVal top{readlane_u64(nm, 0), readlane_u64(nm, 1), readlane_u64(nm, 2), nneg}, n0v{0, 0, 0, false};
+    if (small_chain(t.sc, cand, l, lane, top, n0v)) {
+      chain_done = true;
+      nm = lane == 0 ? n0v.w0 : 0;
+      nneg = n0v.neg;
+    }
+  }
+  for (u32 i = l - 1; !chain_done && i-- > 0;) {
     bool pneg;
-    const u64 ta = dbg >= 4 ? clock64() : 0;
+    const u64 ta = dbg >= 4 && dbg <= 6 ? clock64() : 0;
     u64 p = sub_centre(nm, nneg, Tl[(size_t)i * 64 + lane], pneg);
-    const u64 tb = dbg >= 4 ? clock64() : 0;
+    const u64 tb = dbg >= 4 && dbg <= 6 ? clock64() : 0;
     u64 hi = p >> 63, lo2 = p << 1;                     // 2|p| + Delta
     u64 sm = lo2 + dlw;
     u64 num = wave_normalize(sm, hi + (sm < dlw), 0, lane);
-    const u64 tc = dbg >= 4 ? clock64() : 0;
+    const u64 tc = dbg >= 4 && dbg <= 6 ? clock64() : 0;
     wave_divmod2(c, num, smallL + (2 * W + 2), tdw, dn_td, qq, r);
-    if (dbg >= 4 && i == l - 3) {                       // timing experiment: one step of the chain in three parts
+    if (dbg >= 4 && dbg <= 6 && i == l - 3) {                       // timing experiment: one step of the chain in three parts
       const u64 td2 = clock64();
       if (lane == 0) out[d] = dbg == 4 ? (tb - ta) : (dbg == 5 ? (tc - tb) : (td2 - tc));
       return;
@@ -339,7 +610,7 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
   }
   if (dbg) {
     const u64 tk3 = clock64();
-    if (lane == 0) out[d] = dbg == 1 ? (tk1 - tk0) : (dbg == 2 ? (tk2 - tk1) : (tk3 - tk2));
+    if (lane == 0 && dbg < 8) out[d] = dbg == 1 ? (tk1 - tk0) : (dbg == 2 ? (tk2 - tk1) : (dbg == 7 ? (tk1 - tk0b) : (tk3 - tk2)));
     return;
   }
   const bool vzero = __ballot(v != 0) == 0;

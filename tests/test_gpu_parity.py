@@ -706,6 +706,28 @@ def device_decode_case(l, moduli, select_variant, variants):
               m.delta_power_l_minus_1, D, D // 2, D // 2 + 1):
         cases.append([v % Q] * l)
         cases.append([(v * (j + 1)) % Q for j in range(l)])
+    # the short cut for noise-sized chain inputs (small_candidates / small_confirm) settles tmp_i = z_i*Delta - z_{i+1}
+    # (and z_0) from the first 2..4 residues when the value fits half the product of those moduli, and confirms it against
+    # every limb: inputs whose tmp_i sit on and around that bound for each possible count, either sign, in every / the
+    # first / the last / alternating positions (a refused short cut sends the rest of that wave's inputs the long way)
+    for nl in range(2, min(4, len(moduli) - 1) + 1):
+        Pn = 1
+        for q in moduli[:nl]:
+            Pn *= q
+        # ... and on the rounding boundaries of the division by Delta and the operand bound (2^191) of the chain's
+        # short step (small_chain_step), whose quotient must fit one word (it does not for the larger of these values
+        # when Delta is short: refused, the general step takes over)
+        for v in (Pn // 2 - 1, Pn // 2, Pn // 2 + 1, Pn - 1, Pn, Pn + 1, 1, 2 ** 64, 2 ** 128 + 5, D // 2 - 1, D // 2, D // 2 + 1,
+                  D, 3 * D // 2, 3 * D // 2 + 1, D * (2 ** 64 - 1), D * 2 ** 64 - D // 2 - 1, D * 2 ** 64 - D // 2, 2 ** 191 - 1, 2 ** 191, 2 ** 190):
+            for sign in (1, -1):
+                for where in ("all", "first", "last", "alternate", "z0"):
+                    small = [int(x) for x in rng.integers(-1000, 1001, size=l)]
+                    tm = [sign * v if where == "all" or (where == "first" and i == 0) or (where == "last" and i == l - 2) or
+                          (where == "alternate" and i % 8 >= 4) else small[i] for i in range(l - 1)]
+                    z = [(sign * v if where == "z0" else small[l - 1]) % Q]
+                    for i in range(l - 1):
+                        z.append((z[i] * D - tm[i]) % Q)
+                    cases.append(z)
     arr = np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64)
     want = [M.decode_scalar_pvw(z, m) for z in cases]
     assert want == P.decode_scalar_pvw_host(p, arr)

@@ -93,7 +93,11 @@ def test_multi_dealer_encrypt_on_the_integer_valu(D, monkeypatch):
 @pytest.mark.parametrize("l,moduli", [(8, TEST_MODULI), (8, M.bench_moduli(17)), (16, M.bench_moduli(34)), (64, primes_1mod(128, 5))])
 def test_device_decode_forms_match_model(l, moduli, monkeypatch):
     # decode_scalar_pvw_rns (decryption.rs:10-58): the lifted chain (four waves per ciphertext) and one thread per ciphertext
-    T.device_decode_case(l, moduli, lambda v: monkeypatch.setenv("PVW_DECODE_VARIANT", str(v)), (0, 1))
+    # -- and the chain with every lift in full (PVW_DECODE_SMALL=0: no short cut for noise-sized chain inputs)
+    def select(v):
+        monkeypatch.setenv("PVW_DECODE_VARIANT", "1" if v == 1 else "0")
+        monkeypatch.setenv("PVW_DECODE_SMALL", "0" if v == "full lifts" else "1")
+    T.device_decode_case(l, moduli, select, (0, 1, "full lifts"))
 
 
 @pytest.mark.parametrize("D", [5, 70])
