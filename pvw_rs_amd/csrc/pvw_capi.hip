@@ -281,14 +281,14 @@ static void build_decode_tables(pvw_ctx* c) {
   const size_t W = (c->Q.bits() + 8 + 63) / 64;
   // layout (u64 words): Q | halfQ | qi[L][W] | inv[L] | invp[L] | pow64[L][W] | dmod[L] | dmodp[L] |
   //                     delta | dpow | half_dpow | dpow_n | td_n
-  const size_t total = 2 * W + L * W + 2 * L + L * W + 2 * L + 5 * W + W * L + 3 * (W + 2) + 56 + 9;
+  const size_t total = 2 * W + L * W + 2 * L + L * W + 2 * L + 5 * W + W * L + 3 * (W + 2) + 56 + 9 + 4 * L;
   c->dec_words.assign(total, 0);
   u64* p = c->dec_words.data();
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += n; return o; };
   const size_t oQ = take(W), oH = take(W), oQi = take(L * W), oInv = take(L), oInvp = take(L), oPow = take(L * W),
                oDm = take(L), oDmp = take(L), oDelta = take(W), oDpow = take(W), oHalfD = take(W), oDpn = take(W), oTdn = take(W),
-               oPowT = take(W * L), oTd = take(W + 2), oMuTd = take(W + 2), oMuDp = take(W + 2), oGar = take(56), oSc = take(9);
+               oPowT = take(W * L), oTd = take(W + 2), oMuTd = take(W + 2), oMuDp = take(W + 2), oGar = take(56), oSc = take(9), oDpm = take(4 * L);
   bn_words(c->Q, W, p + oQ);
   bn_words(c->halfQ, W, p + oH);
   for (size_t i = 0; i < L; ++i) {
@@ -369,13 +369,29 @@ static void build_decode_tables(pvw_ctx* c) {
       bn_words(c->delta, 3, sc + 6);
     }
   }
+  // Delta^(l-1) mod q_i, its inverse
+  {
+    bool all_inv = true;
+    for (size_t i = 0; i < L; ++i) {
+      const u64 q = c->moduli[i], v = c->delta_pow.mod_small(q);
+      p[oDpm + i] = v;
+      p[oDpm + L + i] = shoup_precompute(v, q);
+      const u64 inv = v ? powmod(v, q - 2, c->mods[i]) : 0;
+      if (!v) all_inv = false;
+      p[oDpm + 2 * L + i] = inv;
+      p[oDpm + 3 * L + i] = shoup_precompute(inv, q);
+    }
+    // e Delta^(l-1) + g must stay inside (-Q/2, Q/2) for every |e| <= q_0/2 < 2^61, |g| <= Delta/2
+    const bool room = BigInt::cmp(c->halfQ, c->delta_pow.shl(61) + c->delta) > 0;
+    t.hs_on = (t.sc_on && all_inv && room && c->l >= 3 && c->moduli[0] < (1ULL << 62)) ? 1 : 0;
+  }
   auto bind = [&](DecodeTables& d, const u64* base, const Mod* mods) {
     d = t;
     d.mods = mods;
     d.Q = base + oQ; d.halfQ = base + oH; d.qi = base + oQi; d.inv = base + oInv; d.invp = base + oInvp;
     d.pow64 = base + oPow; d.dmod = base + oDm; d.dmodp = base + oDmp; d.delta = base + oDelta;
     d.dpow = base + oDpow; d.half_dpow = base + oHalfD; d.dpow_n = base + oDpn; d.td_n = base + oTdn;
-    d.pow64T = base + oPowT; d.td = base + oTd; d.mu_td = base + oMuTd; d.mu_dp = base + oMuDp; d.gar = base + oGar; d.sc = base + oSc;
+    d.pow64T = base + oPowT; d.td = base + oTd; d.mu_td = base + oMuTd; d.mu_dp = base + oMuDp; d.gar = base + oGar; d.sc = base + oSc; d.dpm = base + oDpm;
   };
   bind(c->dec_host, p, c->mods.data());
   c->dec_dev = t;   // pointers bound at upload
@@ -431,7 +447,7 @@ static int32_t upload_tables(pvw_ctx* c) {
     d.Q = mv(d.Q); d.halfQ = mv(d.halfQ); d.qi = mv(d.qi); d.inv = mv(d.inv); d.invp = mv(d.invp); d.pow64 = mv(d.pow64);
     d.dmod = mv(d.dmod); d.dmodp = mv(d.dmodp); d.delta = mv(d.delta); d.dpow = mv(d.dpow); d.half_dpow = mv(d.half_dpow);
     d.dpow_n = mv(d.dpow_n); d.td_n = mv(d.td_n);
-    d.pow64T = mv(d.pow64T); d.td = mv(d.td); d.mu_td = mv(d.mu_td); d.mu_dp = mv(d.mu_dp); d.gar = mv(d.gar); d.sc = mv(d.sc);
+    d.pow64T = mv(d.pow64T); d.td = mv(d.td); d.mu_td = mv(d.mu_td); d.mu_dp = mv(d.mu_dp); d.gar = mv(d.gar); d.sc = mv(d.sc); d.dpm = mv(d.dpm);
     c->dec_dev = d;
   }
   PVW_HIP(hipDeviceSynchronize());

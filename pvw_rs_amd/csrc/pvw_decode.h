@@ -59,6 +59,11 @@ struct DecodeTables {
   // of its top word, floor((2^128 - 1) / d2) - 2^64 | [4] whole words of that shift | [5] bits of it | [6..8] Delta
   u32 sc_on;
   const u64* sc;      // [9]
+  // Delta^(l-1) mod q_i and its inverse, each with its Shoup companion: [4][L] = value | companion | inverse | companion.
+  // The Horner value telescopes, sum_i tmp_i Delta^(l-2-i) = z_0 Delta^(l-1) - z_{l-1}; the inverse serves the short cut
+  // for noise_{l-1} (hs_on: every limb's inverse exists, Delta has at least 64 bits, sc_on)
+  u32 hs_on;
+  const u64* dpm;     // [4][L]
 };
 
 PVW_HD void bn_zero(BN a, int W) { for (int i = 0; i < W; ++i) a[i] = 0; }

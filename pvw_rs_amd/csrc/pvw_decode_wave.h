@@ -343,14 +343,63 @@ __device__ __forceinline__ bool small_chain_step(const u64* sc, const SmallVal& 
   qneg = pneg && qh != 0;
   return ok && !below;
 }
+// noise_{l-1} without lifting the Horner value.  The reference lifts H = sum_i tmp_i Delta^(l-2-i) (= z_0 Delta^(l-1) -
+// z_{l-1}, the sum telescopes) to (-Q/2, Q/2] and reduces it modulo Delta^(l-1), centred (decryption.rs:30-37, :154-178):
+// a W-word lift and a W-word division for a result that, in a well-formed ciphertext, is a noise value.  Here: GUESS
+// g = the centred remainder of tmp_{l-2} modulo Delta (the same noise value when the ciphertext is well formed), then
+// PROVE it: e_i = (H - g) / Delta^(l-1) mod q_i on every limb must be one small integer e (|e| <= q_0/2, taken from limb
+// 0 and compared on all the others).  Then H = e Delta^(l-1) + g modulo Q, the right-hand side is below Q/2 in magnitude
+// (the host checked 2^61 Delta^(l-1) + Delta < Q/2 before setting hs_on), so it IS the centred H, and with |g| <= Delta/2 <
+// Delta^(l-1)/2 the reference's reduction gives exactly g.  false: nothing assumed, the caller lifts and divides.
+// qv = |round(-tmp_{l-2} / Delta)| comes from the caller (the top lane's chain step on a zero input).
+__device__ __forceinline__ bool small_top(const WaveDecodeCtx& c, const u64* z, const u64* cand, u32 l, u64 qv, SmallVal& top) {
+  const DecodeTables& t = c.t;
+  const u32 lane = c.lane, L = c.L;
+  const u64* cb = cand + (size_t)(l - 2) * 5;
+  // g = b + round(-b/Delta) * Delta = b - sign(b) qv Delta
+  const u64 b0 = cb[0], b1 = cb[1], b2 = cb[2];
+  const bool bneg = (cb[4] & 1) != 0;
+  const u128 t0 = (u128)qv * t.sc[6], t1 = (u128)qv * t.sc[7] + (u64)(t0 >> 64), t2 = (u128)qv * t.sc[8] + (u64)(t1 >> 64);
+  const u128 pl = ((u128)(u64)t1 << 64) | (u64)t0, ph = t2;                  // qv * Delta, 256 bits
+  const u128 bl = ((u128)b1 << 64) | b0, bh = b2;
+  const bool bge = bh != ph ? bh > ph : bl >= pl;
+  const u128 xl = bge ? bl : pl, xh = bge ? bh : ph, yl = bge ? pl : bl, yh = bge ? ph : bh;
+  const u128 gl = xl - yl, gh = xh - yh - (xl < yl ? 1 : 0);
+  if ((u64)(gh >> 63) != 0) return false;                           // |g| must stay below 2^191
+  const u64 g0 = (u64)gl, g1 = (u64)(gl >> 64), g2 = (u64)gh;
+  const bool gneg = (g0 | g1 | g2) != 0 && (bge ? bneg : !bneg);
+  // every limb: H_i, g_i, e_i
+  const u32 li = c.limb_on ? lane : 0;
+  const u64 q = c.m.q;
+  const u64 hi = submod(mulmod_shoup(z[0], t.dpm[li], t.dpm[L + li], q), z[l - 1], q);
+  const u64* pw = c.powL + li;
+  const u128 gs = (u128)g0 * pw[0] + (u128)g1 * pw[64] + (u128)g2 * pw[128];
+  u64 gi = reduce128((u64)gs, (u64)(gs >> 64), c.m);
+  if (gneg && gi) gi = q - gi;
+  const u64 ei = mulmod_shoup(submod(hi, gi, q), t.dpm[2 * L + li], t.dpm[3 * L + li], q);
+  const u64 e0 = readlane_u64(ei, 0), q0 = t.mods[0].q;
+  const bool eneg = e0 > (q0 >> 1);
+  const u64 emag = eneg ? q0 - e0 : e0;
+  u64 want = reduce128(emag, 0, c.m);
+  if (eneg && want) want = q - want;
+  if (__ballot(c.limb_on && want != ei)) return false;
+  top.w0 = g0; top.w1 = g1; top.w2 = g2; top.neg = gneg;
+  return true;
+}
 // The whole chain for noise-sized values.  The steps are serial by definition -- noise_i needs noise_{i+1} -- but for
 // a well-formed ciphertext noise_{i+1} is ~2^-100 of tmp_i and moves round((noise_{i+1} - tmp_i)/Delta) only on a
 // rounding boundary.  So lane i takes step i with a guess for its input (first pass: 0; later passes: what the lane
-// above produced in the pass before; the top lane always has the true noise_{l-1}), all lanes at once, until a pass
+// above produced in the pass before; the top lane has the true noise_{l-1}), all lanes at once, until a pass
 // reproduces the one before.  That fixed point IS the chain: the top lane's input is exact, hence its output, hence the
-// input the next lane used in the confirming pass, and so on down.  false (nothing assumed) when a step does not fit the
-// short form or the passes do not settle in `max_pass`; the caller then walks the chain step by step.
-__device__ __forceinline__ bool small_chain(const u64* sc, const u64* cand, u32 l, u32 lane, const SmallVal& top, SmallVal& out) {
+// input the next lane used in the confirming pass, and so on down.  The top input is either given (top_known: the
+// caller reduced the lifted Horner value) or found here from the first pass (small_top; the top lane's output on a
+// zero input is then already its true output, since noise_{l-1} - tmp_{l-2} is an exact multiple of Delta).
+// false (nothing assumed) when a step does not fit the short form, the top input cannot be proven or the passes do not
+// settle in `max_pass`; `top` then still holds a proven noise_{l-1} if *top_known came back true.
+__device__ __forceinline__ bool small_chain(const WaveDecodeCtx& c, const u64* z, const u64* cand, u32 l, bool* top_known,
+                                            SmallVal& top, SmallVal& out) {
+  const u32 lane = c.lane;
+  const u64* sc = c.t.sc;
   const bool mine = lane + 1 < l;                          // steps 0 .. l-2
   const u64* cb = cand + (size_t)(mine ? lane : 0) * 5;
   u64 q = 0;
@@ -361,7 +410,7 @@ __device__ __forceinline__ bool small_chain(const u64* sc, const u64* cand, u32 
     a.w0 = lane_down1_u64(q);                              // lane i <- lane i+1
     a.w1 = a.w2 = 0;
     a.neg = lane_down1((u32)qneg) != 0;
-    if (lane + 2 == l) a = top;
+    if (lane + 2 == l && *top_known) a = top;
     u64 nq;
     bool nneg;
     const bool ok = small_chain_step(sc, a, cb, nq, nneg);
@@ -369,6 +418,11 @@ __device__ __forceinline__ bool small_chain(const u64* sc, const u64* cand, u32 
     const bool same = nq == q && nneg == qneg;
     q = nq;
     qneg = nneg;
+    if (!*top_known) {                                     // first pass, every input zero
+      if (!c.t.hs_on || !small_top(c, z, cand, l, readlane_u64(q, l - 2), top)) return false;
+      *top_known = true;
+      continue;
+    }
     if (pass > 0 && __ballot(mine && !same) == 0) {
       out.w0 = readlane_u64(q, 0);
       out.w1 = out.w2 = 0;
@@ -452,11 +506,8 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
   u64* zs = Tl + (size_t)(l + 1) * 64;                   // [L][l]
   u64* cand = zs + (size_t)L * l;                        // [l][5]: four words + sign per chain input
   u32* next_input = reinterpret_cast<u32*>(cand + (size_t)5 * l);
-  for (u32 x = threadIdx.x; x < L * W; x += nw * 64) qiL[x] = t.qi[x];
-  for (u32 x = threadIdx.x; x < 2 * W + 2; x += nw * 64) {
-    smallL[x] = x < W + 2 ? t.mu_dp[x] : 0;
-    smallL[(2 * W + 2) + x] = x < W + 2 ? t.mu_td[x] : 0;
-  }
+  // the residues and the power rows first: all the candidates need.  The tables of the full lifts and the general
+  // divisions are staged by the other waves while each ciphertext's first wave works the candidates out.
   for (u32 x = threadIdx.x; x < 256; x += nw * 64) gpowL[x] = ((x & 63) < L && (x >> 6) < W) ? t.pow64T[(size_t)(x >> 6) * L + (x & 63)] : 0;
   const u32 d = blk * cpw + cw;
   const bool live = d < count;                           // uniform over the ciphertext's waves
@@ -477,10 +528,18 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
   // in full: it is of the order of Delta^(l-1)).
   bool hneg = false;
   const bool small_on = t.gar_n != 0 && !no_small;
+  if (wsub != 0) {
+    const u32 nst = (WPC - 1) * cpw * 64, me = (cw * (WPC - 1) + wsub - 1) * 64 + lane;
+    for (u32 x = me; x < L * W; x += nst) qiL[x] = t.qi[x];
+    for (u32 x = me; x < 2 * W + 2; x += nst) {
+      smallL[x] = x < W + 2 ? t.mu_dp[x] : 0;
+      smallL[(2 * W + 2) + x] = x < W + 2 ? t.mu_td[x] : 0;
+    }
+  }
   if (live) {
     if (wsub == 0) {
       const u64 tc0 = dbg == 9 ? clock64() : 0;
-      if (lane == 0) *next_input = 0;
+      if (lane == 0) { next_input[0] = 0; next_input[1] = 0; }
       if (small_on && lane < l) small_candidates(c, zs, l, lane + 1 < l ? lane : l, cand + (size_t)lane * 5);
       if (dbg == 9) {                                    // timing experiment: the candidates
         const u64 tc1 = clock64();
@@ -489,26 +548,33 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
     }
   }
   __syncthreads();
-  if (live) {
-    if (wsub == WPC - 1) {
-      const u64 tl0 = dbg == 10 ? clock64() : 0;
-      bool ng = false;
-      u64 h = tmp(0);                                    // Horner over tmp_0 .. tmp_{l-2} (:30-33)
-      for (u32 i = 1; i + 1 < l; ++i) h = addmod(mulmod_shoup(h, dm, dmp, q), tmp(i), q);
-      const u64 x = wave_lift_centered<true>(c, h, ng);
-      if (lane == 0) Tl[(size_t)(l - 1) * 64 + 63] = ng ? 1 : 0;      // word 63 is never a value word (W + 2 <= 64)
-      if (lane < 63) Tl[(size_t)(l - 1) * 64 + lane] = (lane < W) ? x : 0;
-      if (dbg == 10) {                                   // timing experiment: Horner value and its full lift
-        const u64 tl1 = clock64();
-        if (lane == 0) out[d] = tl1 - tl0;
-      }
+  u32* h_done = next_input + 1;                          // the Horner value sits lifted in its slot
+  // Horner value (:30-33): sum_i tmp_i Delta^(l-2-i) telescopes to z_0 Delta^(l-1) - z_{l-1}; lifted in full, centred
+  auto lift_horner = [&]() {
+    const u64 tl0 = dbg == 10 ? clock64() : 0;
+    bool ng = false;
+    const u32 li = c.limb_on ? lane : 0;
+    const u64 h = submod(mulmod_shoup(z[0], t.dpm[li], t.dpm[L + li], q), z[l - 1], q);
+    const u64 x = wave_lift_centered<true>(c, h, ng);
+    if (lane == 0) {
+      Tl[(size_t)(l - 1) * 64 + 63] = ng ? 1 : 0;        // word 63 is never a value word (W + 2 <= 64)
+      *h_done = 1;
     }
+    if (lane < 63) Tl[(size_t)(l - 1) * 64 + lane] = (lane < W) ? x : 0;
+    if (dbg == 10) {                                     // timing experiment: the Horner value's full lift
+      const u64 tl1 = clock64();
+      if (lane == 0) out[d] = tl1 - tl0;
+    }
+  };
+  if (live) {
     bool try_small = small_on;
-    for (bool first = true;; first = false) {
+    bool first = true;
+    // settle the next chain input: 1 = by its confirmed candidate, 0 = by a full lift, -1 = none left
+    auto settle_next = [&]() -> int {
       u32 idx = 0;
       if (lane == 0) idx = atomicAdd(next_input, 1u);
       idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
-      if (idx >= l) break;
+      if (idx >= l) return -1;
       const u32 item = idx + 1 < l ? idx : l;            // slot l-1 of the lifts is the Horner value's
       const u64 tl0 = dbg == 8 ? clock64() : 0;
       const u64 res = item < l ? tmp(item) : z[0];
@@ -524,7 +590,16 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
         const u64 tl1 = clock64();
         if (lane == 0) out[d] = tl1 - tl0;
       }
+      first = false;
+      return done ? 1 : 0;
+    };
+    if (wsub == WPC - 1) {
+      // the last wave lifts the Horner value now -- unless the ciphertext looks well formed (its first input was settled
+      // by its candidate) and noise_{l-1} can be had without it (small_top); should that fail, the first wave lifts it later
+      const int r = (small_on && t.hs_on) ? settle_next() : 0;
+      if (r != 1) lift_horner();
     }
+    while (settle_next() >= 0) {}
   }
   __syncthreads();
   const u64 tk1 = dbg ? clock64() : 0;
@@ -535,18 +610,44 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
   const u64 tdw = lane < W ? t.td[lane] : 0, dlw = lane < W ? t.delta[lane] : 0;
   const unsigned long long bdp = __ballot(dpw != 0), btd = __ballot(tdw != 0);
   const u32 dn_dp = bdp ? 64 - __builtin_clzll(bdp) : 1, dn_td = btd ? 64 - __builtin_clzll(btd) : 1;
-  hneg = Tl[(size_t)(l - 1) * 64 + 63] != 0;
-  u64 x = lane < 63 ? Tl[(size_t)(l - 1) * 64 + lane] : 0;
-  // reduce_modulo_poly (:154-178): noise_{l-1} = (nm, nneg)
   u64 qq, r;
-  wave_divmod2(c, x, smallL, dpw, dn_dp, qq, r);
-  bool nneg = hneg;
-  if (__ballot(r != 0) == 0) nneg = false;
-  if (wave_cmp(r, hdw) > 0) {
-    r = wave_sub(dpw, r, lane);
-    nneg = !nneg;
+  u64 nm = 0;
+  bool nneg = false;
+  // noise_{l-1} and the chain noise_i = round((noise_{i+1} - tmp_i) / Delta), i = l-2 .. 0 (:30-48, :154-207).
+  // First on noise-sized values throughout: noise_{l-1} proven from the residues (small_top), all steps at once
+  // (small_chain).  Whatever part of that does not apply is done the long way: the Horner value lifted (by the last wave
+  // earlier, or here) and reduced modulo Delta^(l-1); the steps one by one on W-word integers.
+  bool chain_done = false, top_known = false;
+  SmallVal top{0, 0, 0, false}, n0v{0, 0, 0, false};
+  if (small_on && t.hs_on) chain_done = small_chain(c, z, cand, l, &top_known, top, n0v);
+  if (!chain_done) {
+    if (top_known) {
+      nm = lane == 0 ? top.w0 : (lane == 1 ? top.w1 : (lane == 2 ? top.w2 : 0));
+      nneg = top.neg;
+    } else {
+      if (*h_done == 0) lift_horner();
+      hneg = Tl[(size_t)(l - 1) * 64 + 63] != 0;
+      u64 x = lane < 63 ? Tl[(size_t)(l - 1) * 64 + lane] : 0;
+      // reduce_modulo_poly (:154-178): noise_{l-1} = (nm, nneg)
+      wave_divmod2(c, x, smallL, dpw, dn_dp, qq, r);
+      nneg = hneg;
+      if (__ballot(r != 0) == 0) nneg = false;
+      if (wave_cmp(r, hdw) > 0) {
+        r = wave_sub(dpw, r, lane);
+        nneg = !nneg;
+      }
+      nm = r;
+      if (small_on && t.sc_on && l >= 2 && __ballot(lane >= 3 && nm != 0) == 0) {
+        top = SmallVal{readlane_u64(nm, 0), readlane_u64(nm, 1), readlane_u64(nm, 2), nneg};
+        top_known = true;
+        chain_done = small_chain(c, z, cand, l, &top_known, top, n0v);
+      }
+    }
   }
-  u64 nm = r;
+  if (chain_done) {
+    nm = lane == 0 ? n0v.w0 : 0;
+    nneg = n0v.neg;
+  }
   const u64 tk2 = dbg ? clock64() : 0;
   // (a - b) mod Q, centred, for a given as signed magnitude (am, aneg), |a| < Q, and b in [0, Q)
   auto sub_centre = [&](u64 am, bool aneg, u64 b, bool& vneg) -> u64 {
@@ -560,17 +661,6 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
     }
     return v;
   };
-  // noise_i = round((noise_{i+1} - tmp_i) / Delta), i = l-2 .. 0   (:44-48, :180-207): all steps at once while the values
-  // are noise-sized (small_chain), else step by step, one word per lane
-  bool chain_done = false;
-  if (small_on && t.sc_on && l >= 2 && __ballot(lane >= 3 && nm != 0) == 0) {
-    SmallVal top{readlane_u64(nm, 0), readlane_u64(nm, 1), readlane_u64(nm, 2), nneg}, n0v{0, 0, 0, false};
-    if (small_chain(t.sc, cand, l, lane, top, n0v)) {
-      chain_done = true;
-      nm = lane == 0 ? n0v.w0 : 0;
-      nneg = n0v.neg;
-    }
-  }
   for (u32 i = l - 1; !chain_done && i-- > 0;) {
     bool pneg;
     const u64 ta = dbg >= 4 && dbg <= 6 ? clock64() : 0;

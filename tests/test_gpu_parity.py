@@ -728,6 +728,16 @@ def device_decode_case(l, moduli, select_variant, variants):
                     for i in range(l - 1):
                         z.append((z[i] * D - tm[i]) % Q)
                     cases.append(z)
+    # noise_{l-1} without the Horner value's lift (small_top): ciphertext-shaped inputs z_j = -m Delta^j + n_j whose top
+    # noise n_{l-1} sits on the rounding boundaries of Delta, and whose n_0 (the multiple of Delta^(l-1) the proof finds on
+    # every limb) sits on and beyond what one limb can carry
+    q0 = moduli[0]
+    for top_noise in (0, 1, -1, D // 2 - 1, D // 2, D // 2 + 1, -(D // 2 - 1), -(D // 2), -(D // 2 + 1), 2 ** 100, -(2 ** 100)):
+        for n0 in (0, 5, -7, q0 // 2 - 1, q0 // 2, q0 // 2 + 1, -(q0 // 2), -(q0 // 2 + 1), q0, 2 ** 61, 2 ** 64 + 3):
+            msg = int(rng.integers(0, 2 ** 63))
+            noise = [int(x) for x in rng.integers(-5000, 5001, size=l)]
+            noise[0], noise[l - 1] = n0, top_noise
+            cases.append([(-(msg * D ** j) + noise[j]) % Q for j in range(l)])
     arr = np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64)
     want = [M.decode_scalar_pvw(z, m) for z in cases]
     assert want == P.decode_scalar_pvw_host(p, arr)
