@@ -162,6 +162,7 @@ struct pvw_ctx {
   std::vector<u64> moduli, psi;
   float variance;
   u64 b1, b2;
+  u32 num_cus = 256;               // of the context's device (set by ensure_device)
   int device;
   u32 party_lo, party_hi, c1_lo, c1_hi;
   BigInt Q, halfQ, delta, delta_pow;
@@ -479,6 +480,7 @@ static int32_t ensure_device(pvw_ctx* c) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(PVW_ERR_INTERNAL, std::string("kernels are built for gfx950 only, device is ") +
                                       prop.gcnArchName);
+  c->num_cus = (u32)prop.multiProcessorCount;
   PVW_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PVW_HIP(init_kernel_attributes());          // per device: dynamic-LDS limits of the decode kernels
   PVW_TRY(upload_tables(c));
@@ -1913,7 +1915,7 @@ int32_t pvw_decode(pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* ou
     if (hipMemcpyAsync(base, noisy, count * c->poly() * 8, hipMemcpyHostToDevice, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "H2D failed");
     if (rc == PVW_OK) {
       ProfScope ps(c, "decode", w->stream);
-      if (launch_decode((const u64*)base, (u64*)(base + inb), count, c->dec_dev, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "decode launch failed");
+      if (launch_decode((u64*)base, (u64*)(base + inb), count, c->dec_dev, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "decode launch failed");
     }
     if (rc == PVW_OK && (hipMemcpyAsync(out, base + inb, count * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
                          hipStreamSynchronize(w->stream) != hipSuccess)) rc = fail(PVW_ERR_INTERNAL, "D2H failed");
@@ -1928,7 +1930,7 @@ int32_t pvw_decode_device(pvw_ctx* c, const uint64_t* d_noisy, size_t count, uin
   PVW_TRY(ensure_device(c));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   ProfScope ps(c, "decode", s);
-  PVW_HIP(launch_decode(d_noisy, d_out, count, c->dec_dev, s));
+  PVW_HIP(launch_decode(const_cast<u64*>(d_noisy), d_out, count, c->dec_dev, s));    // power basis in: read only
   return PVW_OK;
 }
 
@@ -2055,15 +2057,25 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
   for (size_t i = 0; i < nch; ++i) {
     const size_t d0 = i * chunk, cnt = (D - d0) < chunk ? (D - d0) : chunk;
     u64* nz = d_noisy + d0 * P;
-    PVW_TRY(decrypt_mac_intt(c, w, d_c1s + d0 * k * P, d_c2col + d0 * P, cnt, nz, s));                          // decryption.rs:257-274, :116
+    bool ntt_domain = false;
+    PVW_TRY(decrypt_mac_only(c, w, d_c1s + d0 * k * P, d_c2col + d0 * P, cnt, nz, s, &ntt_domain));             // decryption.rs:257-274
     hipStream_t ds = s;
     if (overlap) {
       PVW_HIP(hipEventRecord(w->events[i], s));
       PVW_HIP(hipStreamWaitEvent(w->aux, w->events[i], 0));
       ds = w->aux;
     }
+    // The decode can transform back while it stages its input (no launch for decryption.rs:116), at the price of 94
+    // instead of 79 registers.  Taken while its workgroups (two ciphertexts each) are resident all at once anyway; beyond,
+    // and when the decode shares the chip with the next chunk's inner products, the 79-register decode runs behind a
+    // transform launch of its own (on the helper stream when there is one).
+    if (ntt_domain && (overlap || (cnt + 1) / 2 > (size_t)2 * c->num_cus)) {
+      ProfScope pi(c, "intt", ds);
+      PVW_HIP(launch_ntt(nz, cnt, true, c->dt, L, l, ds));
+      ntt_domain = false;
+    }
     ProfScope ps(c, "decode", ds);
-    PVW_HIP(launch_decode(nz, d_out + d0, cnt, c->dec_dev, ds));                                                 // :10-58
+    PVW_HIP(launch_decode(nz, d_out + d0, cnt, c->dec_dev, ds, ntt_domain ? &c->dt : nullptr));                  // :116, :10-58
   }
   if (overlap) {
     PVW_HIP(hipEventRecord(w->events[nch], w->aux));
@@ -2114,10 +2126,17 @@ int32_t pvw_decrypt_batch(pvw_ctx* c, const int64_t* sk, const uint64_t* c1s, co
         rc = fail(PVW_ERR_INTERNAL, "H2D failed");
         break;
       }
-      rc = decrypt_enqueue(c, w, d_sk, d_c1, d_c2, cnt, in_repr, d_nz, w->stream, true);
+      bool ntt_domain = false;
+      rc = decrypt_enqueue(c, w, d_sk, d_c1, d_c2, cnt, in_repr, d_nz, w->stream, true, &ntt_domain);
+      if (rc == PVW_OK && ntt_domain && (cnt + 1) / 2 > (size_t)2 * c->num_cus) {      // as in pvw_decrypt_batch_device
+        ProfScope pi(c, "intt", w->stream);
+        if (launch_ntt(d_nz, cnt, true, c->dt, c->L, c->l, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "intt launch failed");
+        ntt_domain = false;
+      }
       if (rc == PVW_OK) {
         ProfScope ps(c, "decode", w->stream);
-        if (launch_decode(d_nz, d_out, cnt, c->dec_dev, w->stream) != hipSuccess) rc = fail(PVW_ERR_INTERNAL, "decode launch failed");   // decryption.rs:277
+        if (launch_decode(d_nz, d_out, cnt, c->dec_dev, w->stream, ntt_domain ? &c->dt : nullptr) != hipSuccess)
+          rc = fail(PVW_ERR_INTERNAL, "decode launch failed");   // decryption.rs:116, :277
       }
       if (rc == PVW_OK && (hipMemcpyAsync(out_u64 + d0, d_out, cnt * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
                            (noisy_out && hipMemcpyAsync(noisy_out + d0 * P, d_nz, cnt * P * 8, hipMemcpyDeviceToHost, w->stream) != hipSuccess) ||

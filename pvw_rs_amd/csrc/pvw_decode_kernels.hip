@@ -30,10 +30,15 @@ __global__ __launch_bounds__(64) void decode_kernel(const u64* __restrict__ nois
 }
 
 // decode, lifted-chain form (pvw_decode_wave.h): 4 waves per ciphertext, cpw ciphertexts per workgroup
-__global__ __launch_bounds__(512) void decode_chain_kernel(const u64* __restrict__ noisy, u64* __restrict__ out,
-                                                            u32 count, u32 cpw_dbg, DecodeTables t) {
+// XF: the residues arrive in the NTT domain and are transformed back while they are staged (stage_inverse).  A separate
+// instance because the compiler gives it 94 registers where the plain one has 79: at most 80 keep the decode co-resident
+// with decrypt_mac_fw, which the overlapped batch path relies on -- that path uses the plain instance behind launch_ntt.
+template <bool XF>
+__global__ __launch_bounds__(512) void decode_chain_kernel(u64* __restrict__ noisy, u64* __restrict__ out,
+                                                            u32 count, u32 cpw_dbg, DecodeTables t, InverseTables xf) {
   extern __shared__ u64 dws[];
-  decode_chain_body<4>(noisy, out, count, cpw_dbg, t, blockIdx.x, dws);
+  if (!XF) xf.itw = nullptr;
+  decode_chain_body<4>(noisy, out, count, cpw_dbg, t, xf, blockIdx.x, dws);
 }
 
 // Kernels that may ask for more than the default 64 KiB of dynamic LDS.  The attribute is per device and per
@@ -42,7 +47,8 @@ __global__ __launch_bounds__(512) void decode_chain_kernel(const u64* __restrict
 hipError_t init_kernel_attributes() {
   const int big = 160 * 1024;
   hipError_t e = hipFuncSetAttribute((const void*)decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decode_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decode_chain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decode_chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
 #if PVW_TUNING
   if (e == hipSuccess) e = init_probe_attributes();
 #endif
@@ -54,8 +60,10 @@ static size_t decode_chain_lds(const DecodeTables& t, u32 cpw, u32 wpc) {
   return ((size_t)t.L * t.W + 2 * (2 * t.W + 2) + 256 + (size_t)cpw * ((size_t)(t.ell + 1) * 64 + (size_t)t.L * t.ell + (size_t)5 * t.ell + 2)) * 8;
 }
 
-hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s) {
+hipError_t launch_decode(u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s, const DevTables* xf) {
   if (count == 0) return hipSuccess;
+  InverseTables inv{nullptr, nullptr, nullptr, nullptr};
+  if (xf) inv = InverseTables{xf->itw, xf->itwp, xf->linv, xf->linvp};
   // by shape: the lifted chain (4 waves per ciphertext, 2 ciphertexts per workgroup) while L <= 64 and W + 2 <= 63
   // (Q up to ~3900 bits) and its tables fit the LDS; one thread per ciphertext beyond (tuning build: PVW_DECODE_VARIANT=1
   // forces it).
@@ -68,9 +76,14 @@ hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeT
       // tuning build only: PVW_DECODE_TIMING=1..6: out[] = cycles of a phase (results are NOT values; tools/decode_timing.py)
       const u32 dbg = (u32)PVW_ENV_INT("PVW_DECODE_TIMING", 0);
       const u32 no_small = PVW_ENV_INT("PVW_DECODE_SMALL", 1) == 0 ? 1u << 31 : 0;     // tuning build: every lift in full
-      decode_chain_kernel<<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | ((dbg & 0xff) << 16) | no_small, t);
+      if (xf) decode_chain_kernel<true><<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | ((dbg & 0xff) << 16) | no_small, t, inv);
+      else decode_chain_kernel<false><<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | ((dbg & 0xff) << 16) | no_small, t, inv);
       return hipGetLastError();
     }
+  }
+  if (xf) {                                              // the fixed-width form has no transform of its own
+    hipError_t e = launch_ntt(noisy, count, true, *xf, t.L, t.ell, s);
+    if (e != hipSuccess) return e;
   }
   const size_t lds = (size_t)(2 * t.W + 1 + t.L) * 64 * sizeof(u64);
   if (lds > 160 * 1024) return hipErrorInvalidValue;

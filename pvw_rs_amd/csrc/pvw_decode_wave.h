@@ -484,9 +484,58 @@ __device__ __forceinline__ void wave_divmod2(const WaveDecodeCtx& c, u64 n, cons
 // ciphertext's first wave -- instead of the INTT launch between the inner products and the decode.  The step did not
 // move (499.8 vs 497 us at the config-5 shard: the decode grew by what the launch had cost) and the extra registers
 // ended the co-residency with decrypt_mac that the overlapped batch path lives on (config 5 in full: 4.05 vs 3.10 ms).)
+// tables of the inverse transform when the decode does it itself (itw == nullptr: the input is in power basis already)
+struct InverseTables {
+  const u64* itw;    // [L][l]  psi^-bitrev(i)
+  const u64* itwp;
+  const u64* linv;   // [L]     l^-1 mod q
+  const u64* linvp;
+};
+// Staging of one ciphertext's residues when they arrive in the NTT domain: the inverse transform of decrypt
+// (decryption.rs:116) on the way into LDS.  ntt_inverse's butterflies (pvw_arith.h), one per thread and stage, l/2
+// consecutive threads per polynomial: they load it, share a wave (l/2 divides 64), and a wave's LDS accesses execute in
+// order, so neither the load nor the stages need a barrier.  The power-basis polynomial replaces the input in memory.
+__device__ __forceinline__ void stage_inverse(const Mod* mods, const InverseTables& xf, u64* zs, u64* dst, u32 L, u32 l,
+                                                        u32 first, u32 stride) {
+  const u32 half = l >> 1, npair = L * half, lh = (u32)__builtin_ctz(half);       // l is a power of two
+#pragma unroll 1
+  for (u32 x = first; x < ((npair + 63) & ~63u); x += stride) {
+    const bool on = x < npair;
+    const u32 limb = on ? x >> lh : 0, b = x & (half - 1);
+    const u64 q = mods[limb].q;
+    u64* a = zs + (size_t)limb * l;
+    if (on) {                                              // the polynomial's l/2 threads bring it in themselves
+      const v2u64 in = reinterpret_cast<const v2u64*>(dst)[x];
+      a[2 * b] = in.x;
+      a[2 * b + 1] = in.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const u64* tw = xf.itw + (size_t)limb * l;
+    const u64* twp = xf.itwp + (size_t)limb * l;
+    u32 ls = 0;                                            // step = 1 << ls, mm = half >> ls
+#pragma unroll 1
+    for (u32 mm = half; mm >= 1; mm >>= 1, ++ls) {
+      const u32 i = b >> ls, j = (i << (ls + 1)) + (b & ((1u << ls) - 1));
+      if (on) {
+        const u64 w = tw[mm + i], wp = twp[mm + i];
+        const u64 u = a[j], v = a[j + (1u << ls)];
+        a[j] = addmod(u, v, q);
+        a[j + (1u << ls)] = mulmod_shoup(submod(u, v, q), w, wp, q);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (on) {
+      const u64 li = xf.linv[limb], lip = xf.linvp[limb];
+      const u64 r0 = mulmod_shoup(a[2 * b], li, lip, q), r1 = mulmod_shoup(a[2 * b + 1], li, lip, q);
+      a[2 * b] = r0;
+      a[2 * b + 1] = r1;
+      reinterpret_cast<v2u64*>(dst)[x] = v2u64{r0, r1};
+    }
+  }
+}
 template <int WPC>
-__device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy, u64* __restrict__ out,
-                                                  u32 count, u32 cpw_dbg, const DecodeTables& t, u32 blk, u64* dws) {
+__device__ __forceinline__ void decode_chain_body(u64* __restrict__ noisy, u64* __restrict__ out, u32 count, u32 cpw_dbg,
+                                                  const DecodeTables& t, const InverseTables& xf, u32 blk, u64* dws) {
   const u32 cpw = cpw_dbg & 0xffff;
   const u32 dbg = PVW_TUNING ? ((cpw_dbg >> 16) & 0xff) : 0;
   const bool no_small = PVW_TUNING && (cpw_dbg >> 31);     // tuning build: PVW_DECODE_SMALL=0, every lift in full        // tuning build, dbg != 0: timing experiment, out[] = cycle counts
@@ -511,8 +560,11 @@ __device__ __forceinline__ void decode_chain_body(const u64* __restrict__ noisy,
   for (u32 x = threadIdx.x; x < 256; x += nw * 64) gpowL[x] = ((x & 63) < L && (x >> 6) < W) ? t.pow64T[(size_t)(x >> 6) * L + (x & 63)] : 0;
   const u32 d = blk * cpw + cw;
   const bool live = d < count;                           // uniform over the ciphertext's waves
-  if (live)
-    for (u32 x = wsub * 64 + lane; x < L * l; x += WPC * 64) zs[x] = noisy[(size_t)d * L * l + x];
+  if (live) {
+    if (xf.itw) stage_inverse(t.mods, xf, zs, noisy + (size_t)d * L * l, L, l, wsub * 64 + lane, WPC * 64);
+    else
+      for (u32 x = wsub * 64 + lane; x < L * l; x += WPC * 64) zs[x] = noisy[(size_t)d * L * l + x];
+  }
   __syncthreads();
   const u64 tk0b = dbg ? clock64() : 0;
   WaveDecodeCtx c{t, qiL, gpowL, lane, W, L, t.mods[lane < L ? lane : 0], lane < L, lane < W,

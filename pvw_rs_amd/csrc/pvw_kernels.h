@@ -230,6 +230,9 @@ hipError_t launch_read_probe2(const u64* M, size_t total_tiles, u32 tiles_per_wa
 // per-device kernel attributes (dynamic-LDS limits); call once per context after hipSetDevice
 hipError_t init_kernel_attributes();
 hipError_t launch_mfma_probe(const signed char* A, const signed char* B, int* C, hipStream_t s);
-hipError_t launch_decode(const u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s);
+// xf == nullptr: noisy holds power-basis polynomials (read only).  xf != nullptr: noisy holds them in the NTT domain; the
+// decode transforms each ciphertext back as it stages it and stores the power-basis polynomial over it (the inverse
+// transform of decrypt, decryption.rs:116, without a launch of its own).
+hipError_t launch_decode(u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s, const DevTables* xf = nullptr);
 
 }  // namespace pvw
