@@ -429,7 +429,8 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
     const u32 waves = cfull * FW + crem;
     if (waves >= 1 && waves <= 16) {
       const u32 thr = waves * 64;
-      // two dealers per workgroup, four j-steps in flight (one / three dealers and 2 / 8 steps were measured: r01d_decrypt_sweep)
+      // two dealers per workgroup, four j-steps in flight (one / three dealers and 2 / 8 steps were measured: r01d_decrypt_sweep;
+      // again in round 3 with the register budget varied as well, profiles/r03_decrypt_mac_shapes.txt: 425-735 us against 362-369)
       decrypt_mac_fw_kernel<2, 4><<<dim3((u32)((dealers + 1) / 2), nsplit), dim3(thr), (size_t)2 * thr * sizeof(v2u64), s>>>(
           c1s, shat, c2col, noisy, t.mods, k, ell, pairs, FW, cfull, remp, crem, (u32)dealers, partial);
       return hipGetLastError();

@@ -46,6 +46,45 @@ __global__ __launch_bounds__(64) void prep_kernel(const i64* __restrict__ coeffs
     *reinterpret_cast<v2u64*>(o + s) = (v2u64){a[s], a[s + 1]};
 }
 
+// The same for the plain case (small coefficients -> RNS -> NTT, no scalar, no grouping) with ELL/2 threads per
+// (polynomial, limb) instead of one: thread b brings in coefficients 2b, 2b+1, takes one butterfly per stage of
+// ntt_forward through LDS and stores slots 2b, 2b+1.  The ELL/2 threads are consecutive and share a wave, whose LDS
+// accesses execute in order: no barrier between the stages.  The transform of a decrypt's secret key is k x L short
+// transforms in front of the inner products: with one thread each the launch was 10.5 us of latency at config 5.
+template <int ELL>
+__global__ __launch_bounds__(256) void prep_coop_kernel(const i64* __restrict__ coeffs, u64* __restrict__ out,
+                                                         size_t stride_poly, size_t stride_limb, u32 count, u32 L, DevTables t) {
+  constexpr u32 H = ELL / 2;
+  __shared__ u64 buf[256 / H * ELL];
+  const u32 tid = blockIdx.x * 256 + threadIdx.x;
+  const u32 pl = tid / H, b = tid % H;                   // (polynomial, limb) pair; butterfly
+  const bool on = pl < count * L;
+  const u32 p = on ? pl / L : 0, limb = on ? pl % L : 0;
+  const Mod m = t.mods[limb];
+  u64* a = buf + (threadIdx.x / H) * ELL;
+  if (on) {
+    a[2 * b] = signed_residue(coeffs[(size_t)p * ELL + 2 * b], m);
+    a[2 * b + 1] = signed_residue(coeffs[(size_t)p * ELL + 2 * b + 1], m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const u64* tw = t.tw + (size_t)limb * ELL;
+  const u64* twp = t.twp + (size_t)limb * ELL;
+  u32 step = ELL;
+#pragma unroll
+  for (u32 mm = 1; mm < ELL; mm <<= 1) {
+    step >>= 1;
+    const u32 i = b / step, j = 2 * i * step + (b % step);
+    if (on) {
+      const u64 u = a[j], v = mulmod_shoup(a[j + step], tw[mm + i], twp[mm + i], m.q);
+      a[j] = addmod(u, v, m.q);
+      a[j + step] = submod(u, v, m.q);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (on)
+    *reinterpret_cast<v2u64*>(out + (size_t)p * stride_poly + (size_t)limb * stride_limb + 2 * b) = (v2u64){a[2 * b], a[2 * b + 1]};
+}
+
 // dst[c][j] = src[j][c] over a k x k matrix of polynomials (`words` u64 each): key generation walks the
 // CRS by columns (crs.rs:152-168)
 __global__ __launch_bounds__(256) void transpose_polys_kernel(const u64* __restrict__ src, u64* __restrict__ dst,
@@ -353,6 +392,11 @@ hipError_t launch_prep(const i64* coeffs, const u64* scalars, u64* out, size_t s
                        size_t stride_limb, u32 count, bool do_ntt, const DevTables& t, u32 L,
                        u32 ell, hipStream_t s, u32 group, size_t stride_group) {
   if (count == 0) return hipSuccess;
+  if (do_ntt && !scalars && !group) {
+    const size_t coop = (size_t)count * L * (ell / 2);
+    PVW_DISPATCH_ELL(ell, prep_coop_kernel<E><<<dim3((u32)((coop + 255) / 256)), dim3(256), 0, s>>>(coeffs, out, stride_poly, stride_limb, count, L, t));
+    return hipGetLastError();
+  }
   const u32 threads = count * L;
   PVW_DISPATCH_ELL(ell, prep_kernel<E><<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(coeffs, scalars, out, stride_poly, stride_limb, count, L,
                                             do_ntt ? 1u : 0u, t, group, stride_group));
