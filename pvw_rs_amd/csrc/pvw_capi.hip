@@ -1524,6 +1524,10 @@ static int32_t encrypt_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scalars, c
 // NOTE (measured, round 1): overlapping the prologue of call i with the MAC of call i-1 on a second
 // stream was tried and reverted -- the cross-stream event dependencies cost more (step 242 us vs
 // 207 us at config 3) than the ~14 us prologue they hide.  Single-stream, in-order is the fast path.
+// Round 3, again, with nothing but the seed feeding the prologue (compact addends: it no longer reads the scalars), two
+// sets of (r-hat, addends) and one wait per stream and call: the prologue does run under the previous MAC (26 us there
+// instead of 11), but the MAC behind the cross-stream wait starts as late as it did behind the prologue: step = MAC +
+// 7.6-7.9 us against MAC + 7.8-8.3 us in order (same box, 183-184 us MACs).  Not kept.
 int32_t pvw_encrypt_device(pvw_ctx* c, const uint64_t* d_scalars, size_t num_scalars, const pvw_randomness_t* rnd,
                            uint64_t* d_c1, uint64_t* d_c2, uint32_t out_repr, void* stream) {
   if (!c || !d_scalars || (!d_c1 && c->rowsA()) || (!d_c2 && c->rowsB())) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
