@@ -163,6 +163,7 @@ struct pvw_ctx {
   float variance;
   u64 b1, b2;
   u32 num_cus = 256;               // of the context's device (set by ensure_device)
+  u32 xm_bytes = 8;                // bytes per element in the MFMA-tiled copies xmA / xmB (set when they are built)
   int device;
   u32 party_lo, party_hi, c1_lo, c1_hi;
   BigInt Q, halfQ, delta, delta_pow;
@@ -912,9 +913,12 @@ static int32_t ensure_xm(pvw_ctx* c, hipStream_t s) {
   if (!c->xmB && wb) PVW_HIP(hipMalloc((void**)&c->xmB, wb * 8));
   if (wa) PVW_HIP(hipMemsetAsync(c->xmA, 0, wa * 8, s));
   if (wb) PVW_HIP(hipMemsetAsync(c->xmB, 0, wb * 8, s));
+  // every modulus below 2^56 and k a multiple of 64: the copy holds 7 bytes per element (gemm_ktiles), and multi-dealer
+  // encrypt contracts over 7/8 of the terms.  Tuning build: PVW_GEMM_BYTES=8 keeps all 8.
+  c->xm_bytes = gemm7_ok(c->dt.max_q_bits, c->k) && PVW_ENV_INT("PVW_GEMM_BYTES", 7) != 8 ? 7 : 8;
   ProfScope ps(c, "mftile", s);
-  PVW_HIP(launch_mftile(c->dA, true, c->xmA, rA, c->k, c->L, c->l, s));
-  PVW_HIP(launch_mftile(c->dB, true, c->xmB, rB, c->k, c->L, c->l, s));
+  PVW_HIP(launch_mftile(c->dA, true, c->xmA, rA, c->k, c->L, c->l, s, c->xm_bytes));
+  PVW_HIP(launch_mftile(c->dB, true, c->xmB, rB, c->k, c->L, c->l, s, c->xm_bytes));
   PVW_HIP(hipStreamSynchronize(s));
   c->xm_valid = true;
   return PVW_OK;
@@ -1633,7 +1637,7 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
     if (use_gemm) {
       {
         ProfScope ps(c, "vec_digits", s);
-        PVW_HIP(launch_vec_digits(vh, (size_t)k * P, w->yd, w->sy, nv, k, L, l, c->dt, s));
+        PVW_HIP(launch_vec_digits(vh, (size_t)k * P, w->yd, w->sy, nv, k, L, l, c->dt, s, 0, 0, c->xm_bytes));
       }
       ProfScope ps(c, "gemm_digits", s);
       GemmSection a{c->xmA, c1g, c1g, w->gtmpA, rA, 0, 0}, b{c->xmB, c2g, c2g, w->gtmpB, rB, 0, 0};
@@ -1651,7 +1655,7 @@ static int32_t encrypt_multi_enqueue(pvw_ctx* c, Workspace* w, const u64* d_scal
         }
         b.addend = nullptr;
       }
-      PVW_HIP(launch_gemm_digits(a, b, w->yd, w->sy, c->dt, k, L, l, nv, (size_t)rA * P, (size_t)rB * P, s, nullptr, fused_e2 ? es.data() : nullptr));
+      PVW_HIP(launch_gemm_digits(a, b, w->yd, w->sy, c->dt, k, L, l, nv, (size_t)rA * P, (size_t)rB * P, s, nullptr, fused_e2 ? es.data() : nullptr, c->xm_bytes));
     } else {
       ProfScope ps(c, "mac_rows_multi", s);
       MacSection a{c->dA, c1g, c1g, rA, 0}, b{c->dB, c2g, c2g, rB, 0};

@@ -286,6 +286,134 @@ __global__ __launch_bounds__(64) void vec_digits_kernel(const u64* __restrict__ 
   }
 }
 
+// ---- 7-byte contraction (every modulus below 2^56; gemm_ktiles) ----
+// Byte 7 of every matrix element is zero, so K = (j, a) needs a < 7 only: 7/8 of the MFMAs, of the LDS traffic and of the
+// operand bytes.  The K rows are regrouped so that both producers stay simple: K tile (g, a) = byte position a of the 32
+// consecutive j of group g; row j % 32 of the tile.  A fragment of lane (h, m): byte a of x[row m][32 g + 16 h + p],
+// p = 0..15; digit fragment of lane (h, col = 8 v4 + b): digit b of the shifted copy a of y_v[32 g + 16 h + p].
+// tiled matrix (or API-layout rows) -> XM7[limb][slot][row tile][g*7 + a][lane][16 bytes]; one thread per (row, limb,
+// slot, g, h) reads its 16 elements and writes 7 fragments.  A one-off per matrix (pvw_prepare / first multi-dealer call).
+template <int ELL>
+__global__ __launch_bounds__(256) void mftile7_kernel(const u64* __restrict__ src, u32 src_is_tiled, u64* __restrict__ XM,
+                                                       u32 rows, u32 k, u32 L) {
+  constexpr int R = 128 / ELL;
+  const u32 G = k / 32, KT = 7 * G;
+  const u32 RT = ((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * (PVW_GEMM_ROWS_PER_WG / 32);
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)RT * 32 * L * ELL * G * 2;      // padding rows included: they must hold the offset-zero pattern
+  if (tid >= total) return;
+  const u32 slot = tid % ELL;
+  size_t r = tid / ELL;
+  const u32 row = r % (RT * 32);
+  r /= (RT * 32);
+  const u32 limb = r % L;
+  r /= L;
+  const u32 h = r & 1, g = (u32)(r >> 1);
+  u64 x[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const u32 j = 32 * g + 16 * h + p;
+    u64 v = 0;
+    if (row < rows)
+      v = src_is_tiled ? src[(((size_t)(row / R) * L + limb) * k + j) * 128 + (row % R) * ELL + slot]
+                       : src[(((size_t)row * k + j) * L + limb) * ELL + slot];
+    x[p] = v;
+  }
+  const u32 rt = row >> 5, m = row & 31;
+  u64* base = XM + ((((size_t)limb * ELL + slot) * RT + rt) * KT + (size_t)g * 7) * 128 + (h * 32 + m) * 2;
+#pragma unroll
+  for (int a = 0; a < 7; ++a) {
+    u64 lo = 0, hi = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      lo |= ((x[p] >> (8 * a)) & 0xff) << (8 * p);
+      hi |= ((x[8 + p] >> (8 * a)) & 0xff) << (8 * p);
+    }
+    *reinterpret_cast<v2u64*>(base + (size_t)a * 128) = (v2u64){lo ^ 0x8080808080808080ULL, hi ^ 0x8080808080808080ULL};   // signed-offset, as mftile_kernel
+  }
+}
+// vector elements -> digit tiles YD[vg][limb][slot][g*7 + a][h*32 + 8 v4 + b][16] and the offset correction SY (as
+// vec_digits_kernel; the sum runs over the 7 copies that take part).  One wave per (v, limb, slot); lane = block of 16 j.
+template <int ELL>
+__global__ __launch_bounds__(64) void vec_digits7_kernel(const u64* __restrict__ vhat, size_t vstride,
+                                                          signed char* __restrict__ YD, int* __restrict__ SY,
+                                                          u32 nv, u32 k, u32 L, DevTables t, size_t lstride, size_t jstride) {
+  const u32 lane = threadIdx.x;
+  const u32 slot = blockIdx.x % ELL;
+  const u32 limb = (blockIdx.x / ELL) % L;
+  const u32 v = blockIdx.x / (ELL * L);
+  const Mod m = t.mods[limb];
+  const u32 KT = 7 * (k / 32);
+  const u32 vg = v >> 2, v4 = v & 3;
+  const u64 w256p = (m.ratio_hi << 8) | (m.ratio_lo >> 56);   // floor(256 * 2^64 / q)
+  const u64* y = vhat + (size_t)v * vstride + (size_t)limb * lstride + slot;
+  signed char* tiles = YD + (((size_t)vg * L + limb) * ELL + slot) * (size_t)KT * 1024;
+  u64 csum_lo = 0;
+  u32 csum_hi = 0;
+  __shared__ v4i32 st[64 * 8];                                  // one byte position's runs of the wave, 8 KiB
+  const u32 nblk = k / 16;
+  for (u32 jb0 = 0; jb0 < nblk; jb0 += 64) {                    // whole passes: every lane takes part in the staging
+    const u32 jb = jb0 + lane;
+    const bool on = jb < nblk;
+    u64 cur[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) cur[p] = on ? y[(size_t)(16 * jb + p) * jstride] : 0;
+#pragma unroll 1
+    for (u32 a = 0; a < 7; ++a) {
+      const u64 C = 0x8080808080808080ULL;
+      u32 lo[16], hi[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const u64 dgt = (cur[p] + C) ^ C;                       // the 8 balanced digits as bytes (vec_digits_kernel)
+        lo[p] = (u32)dgt;
+        hi[p] = (u32)(dgt >> 32);
+        csum_lo += cur[p];
+        csum_hi += csum_lo < cur[p];
+        cur[p] = mulmod_shoup(cur[p], 256, w256p, m.q);
+      }
+      // digit b of the 16 elements = one 16-byte run: byte transposes of four elements at a time
+      u32 run[8][4];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        transpose4x4_bytes(lo[4 * qd], lo[4 * qd + 1], lo[4 * qd + 2], lo[4 * qd + 3], run[0][qd], run[1][qd], run[2][qd], run[3][qd]);
+        transpose4x4_bytes(hi[4 * qd], hi[4 * qd + 1], hi[4 * qd + 2], hi[4 * qd + 3], run[4][qd], run[5][qd], run[6][qd], run[7][qd]);
+      }
+      // this lane's 8 runs are 128 contiguous bytes of its tile (rows h*32 + 8 v4 .. + 7); through LDS so that lanes
+      // 8x .. 8x+7 of one store instruction write them as one line (the piece index XORed against bank conflicts)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        st[lane * 8 + (b ^ (lane & 7))] = (v4i32){(int)run[b][0], (int)run[b][1], (int)run[b][2], (int)run[b][3]};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (u32 it = 0; it < 8; ++it) {
+        const u32 sl = it * 8 + (lane >> 3), b = lane & 7, sjb = jb0 + sl;       // source lane, its block of 16 j
+        const v4i32 val = st[sl * 8 + (b ^ (sl & 7))];
+        if (sjb < nblk)
+          *reinterpret_cast<v4i32*>(tiles + (size_t)((sjb >> 1) * 7 + a) * 1024 + (size_t)((sjb & 1) * 32 + v4 * 8 + b) * 16) = val;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const u64 olo = ((u64)__shfl_xor((u32)(csum_lo >> 32), d) << 32) | __shfl_xor((u32)csum_lo, d);
+    const u32 ohi = __shfl_xor(csum_hi, d);
+    csum_lo += olo;
+    csum_hi += ohi + (csum_lo < olo);
+  }
+  if (lane == 0) {
+    const u64 r = reduce128(csum_lo, (u64)csum_hi, m);
+    u64 corr = mulmod(r, 128, m);
+    if (gemm_biased(k)) {                                    // minus the constant the biased accumulators leave: 2^51 + 2^83
+      const u64 c51 = (1ull << 51) % m.q;
+      const u64 cb = addmod(c51, mulmod(c51, (1ull << 32) % m.q, m), m.q);
+      corr = corr >= cb ? corr - cb : corr + m.q - cb;
+    }
+    reinterpret_cast<u64*>(SY + (((size_t)vg * L + limb) * ELL + slot) * 32)[v4] = corr;
+  }
+}
+
 // One 32x32 accumulator of the digit GEMM (digit tile as first operand: register 4 v4 + bb of lane (h, rr) holds
 // digit b = 4 h + bb of vector v4 for matrix row rr) -> the two finished sums this lane owns,
 //   res[pr] = sum_b C[(v, b)][row] 2^(8b) mod q   for v = pr + 2 h  (pr = 0, 1).
@@ -383,14 +511,14 @@ template <int ELL, int NVG, int RPW, int NCH = 0, bool FASTQ = false>
 __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
                                                            const int* __restrict__ SY, const Mod* __restrict__ mods,
                                                            u32 k, u32 L, u32 nv_total, u32 nv_pad, u32 vbn,
-                                                           size_t yd_b16, size_t sy_b16) {
+                                                           size_t yd_b16, size_t sy_b16, u32 kt) {
   // block = (limb, slot, group of 4*RPW row tiles); the 4 waves share the vector-digit tiles through
   // LDS (CJ j-blocks at a time); each wave owns RPW row tiles of 32 rows and streams their raw u64 tiles.
   constexpr int CJ = 8;                                    // j-blocks per staged chunk (32 MFMAs per wave per barrier)
   constexpr int BSH = NVG * CJ * 64 / 256;                 // 16-byte B elements each thread stages per chunk
   __shared__ v4i32 bl[2][NVG * CJ * 64];                   // two chunks of NVG*CJ KiB
   // NCH != 0: the launcher guarantees k == 4 * NCH * CJ, so every bounds test below folds away
-  const u32 JB = NCH ? (u32)(NCH * CJ) : (k + 3) / 4;
+  const u32 JB = NCH ? (u32)(NCH * CJ) : kt;               // K tiles (gemm_ktiles)
   const bool biased = gemm_biased(k);                      // uniform: see gemm_recombine_biased
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 rtg_total = sa.rt_groups + sb.rt_groups;
@@ -556,7 +684,7 @@ __global__ __launch_bounds__(256) void gemm_digits_kernel(GemmSection sa, GemmSe
 template <int ELL, bool FASTQ>
 __global__ __launch_bounds__(512, 2) void gemm_digits_wide_kernel(GemmSection sa, GemmSection sb, const signed char* __restrict__ YD,
                                                                          const Mod* __restrict__ mods, u32 k, u32 L, u32 nv_total,
-                                                                         u32 nv_pad, u32 vbn, size_t yd_b16) {
+                                                                         u32 nv_pad, u32 vbn, size_t yd_b16, u32 kt) {
   static_assert(PVW_GEMM_RPW == 1, "XM is padded to groups of four row tiles");
   constexpr int WRN = 4, NWV = 2 * WRN;                    // waves: WRN along the rows x 2 batches of 16 vectors
   constexpr int CJ = 2;                                    // j-blocks per stage
@@ -566,7 +694,7 @@ __global__ __launch_bounds__(512, 2) void gemm_digits_wide_kernel(GemmSection sa
   constexpr int GPS = (RTW + NG) * CJ / NWV;               // LDS-DMA instructions per wave per stage: 4 / 6
   __shared__ v4i32 stage[NB * STAGE];                      // ONE array (a second __shared__ object next to LDS-DMA
                                                            // destinations makes hipcc drain the DMAs early)
-  const u32 JB = k / 4, NST = JB / CJ;
+  const u32 JB = kt, NST = JB / CJ;                        // K tiles (gemm_ktiles; even)
   const bool biased = gemm_biased(k);                      // uniform: see gemm_recombine_biased
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 wr = wave >> 1, wv = wave & 1;
@@ -890,8 +1018,14 @@ __global__ __launch_bounds__(32 * VPB) void gemm_finish_err_kernel(GemmSection s
     __builtin_amdgcn_wave_barrier();                             // the staging rows are rewritten for the next limb
   }
 }
-hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s) {
+hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s, u32 bytes) {
   if (rows == 0) return hipSuccess;
+  if (bytes == 7) {
+    const u32 RT = ((rows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG) * (PVW_GEMM_ROWS_PER_WG / 32);
+    const size_t threads = (size_t)RT * 32 * L * ell * (k / 32) * 2;
+    PVW_DISPATCH_ELL(ell, mftile7_kernel<E><<<dim3((u32)((threads + 255) / 256)), dim3(256), 0, s>>>(src, src_is_tiled ? 1u : 0u, XM, rows, k, L));
+    return hipGetLastError();
+  }
   if (!src_is_tiled && ell <= 32) {      // API-layout rows: the LDS-transposing form (writes every tile, padding included)
     const u32 jbg = ell <= 8 ? 4 : (ell == 16 ? 2 : 1);
     const u32 JB = (k + 3) / 4, JG = (JB + jbg - 1) / jbg;
@@ -926,16 +1060,20 @@ hipError_t launch_shat_mftile(const i64* coeffs, u64* XM, u32 rows, u32 k, u32 L
 }
 
 hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
-                             const DevTables& t, hipStream_t s, size_t lstride, size_t jstride) {
+                             const DevTables& t, hipStream_t s, size_t lstride, size_t jstride, u32 bytes) {
   if (nv == 0) return hipSuccess;
   if (lstride == 0 && jstride == 0) { lstride = (size_t)k * ell; jstride = ell; }
   // unused vector slots of the last group must read as zero digits / zero sums
   if (nv % 4) {
-    const u32 NVG = (nv + 3) / 4, JB = (k + 3) / 4;
+    const u32 NVG = (nv + 3) / 4, JB = gemm_ktiles(k, bytes);
     hipError_t e = hipMemsetAsync(YD + (size_t)(NVG - 1) * L * ell * JB * 1024, 0, (size_t)L * ell * JB * 1024, s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(SY + (size_t)(NVG - 1) * L * ell * 32, 0, (size_t)L * ell * 32 * sizeof(int), s);
     if (e != hipSuccess) return e;
+  }
+  if (bytes == 7) {
+    PVW_DISPATCH_ELL(ell, vec_digits7_kernel<E><<<dim3(nv * L * ell), dim3(64), 0, s>>>(vhat, vstride, YD, SY, nv, k, L, t, lstride, jstride));
+    return hipGetLastError();
   }
   // default: stores staged through LDS (whole 128-byte lines per instruction, 16 KiB per wave); PVW_VEC_DIGITS_STAGE=0: direct
 #if PVW_TUNING
@@ -951,8 +1089,9 @@ hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, i
 
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
-                              hipStream_t s, const GemmErrSource* es_a, const GemmErrSource* es_b) {
+                              hipStream_t s, const GemmErrSource* es_a, const GemmErrSource* es_b, u32 bytes) {
   GemmSection sa = a, sb = b;
+  const u32 kt = gemm_ktiles(k, bytes);
   sa.rt_groups = (sa.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
   sb.rt_groups = (sb.nrows + PVW_GEMM_ROWS_PER_WG - 1) / PVW_GEMM_ROWS_PER_WG;
   const u32 blocks = (sa.rt_groups + sb.rt_groups) * L * ell;
@@ -962,11 +1101,11 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   const u32 nv_pad = NVG * 4;
   sa.tmp_bstride = (size_t)L * ell * 16 * sa.rt_groups * PVW_GEMM_ROWS_PER_WG;
   sb.tmp_bstride = (size_t)L * ell * 16 * sb.rt_groups * PVW_GEMM_ROWS_PER_WG;
-  const size_t yd_b16 = yd_bytes(16, k, L, ell), sy_b16 = sy_bytes(16, L, ell) / sizeof(int);
+  const size_t yd_b16 = (size_t)4 * L * ell * kt * 1024, sy_b16 = sy_bytes(16, L, ell) / sizeof(int);
 #define PVW_GEMM_LAUNCH(G, N)                                                                                              \
   do {                                                                                                                    \
-    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, true><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, vbn, yd_b16, sy_b16)); } \
-    else { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, false><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, vbn, yd_b16, sy_b16)); } \
+    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, true><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, vbn, yd_b16, sy_b16, kt)); } \
+    else { PVW_DISPATCH_ELL(ell, gemm_digits_kernel<E, G, PVW_GEMM_RPW, N, false><<<dim3(blocks * vbn), dim3(256), 0, s>>>(sa, sb, YD, SY, t.mods, k, L, nv, nv_pad, vbn, yd_b16, sy_b16, kt)); } \
   } while (0)
 #if PVW_TUNING
   // timing experiment (results wrong): all-zero operand bytes, to separate the schedule from the data-dependent power draw
@@ -979,17 +1118,17 @@ hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const 
   // more than 16 vectors and whole stages of 16 terms: the wide form (256 rows x 32 vectors per workgroup of 8 waves in
   // ping-pong, both operands through LDS).  PVW_GEMM_WIDE=0 in the tuning build selects gemm_digits_kernel everywhere.
   // (8 waves in step and 4 waves x two workgroups per CU were the other forms measured: profiles/r02_gemm_wide.txt.)
-  const bool wide = vbn >= 2 && k % 16 == 0 && k >= 16 && PVW_ENV_INT("PVW_GEMM_WIDE", 1) != 0;
+  const bool wide = vbn >= 2 && k % 16 == 0 && k >= 16 && kt % 2 == 0 && PVW_ENV_INT("PVW_GEMM_WIDE", 1) != 0;
   if (wide) {
     const u32 ga = (sa.rt_groups * 4 + 7) / 8, gb2 = (sb.rt_groups * 4 + 7) / 8;
     const u32 wblocks = (ga + gb2) * L * ell * ((vbn + 1) / 2);
-    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, true><<<dim3(wblocks), dim3(512), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); }
-    else { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, false><<<dim3(wblocks), dim3(512), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16)); }
+    if (t.min_q_bits >= 55) { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, true><<<dim3(wblocks), dim3(512), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16, kt)); }
+    else { PVW_DISPATCH_ELL(ell, gemm_digits_wide_kernel<E, false><<<dim3(wblocks), dim3(512), 0, s>>>(sa, sb, YD, t.mods, k, L, nv, nv_pad, vbn, yd_b16, kt)); }
   } else {
   // fully unrolled chunk loops for the BASELINE geometries (k = 256: 8 chunks of 8 j-blocks, k = 512: 16), full vector groups
   static const int unroll_ok = (int)PVW_ENV_INT("PVW_GEMM_UNROLL", 1);
-  if (NVG == 4 && unroll_ok && k == 256) { PVW_GEMM_LAUNCH(4, 8); }
-  else if (NVG == 4 && unroll_ok && k == 512) { PVW_GEMM_LAUNCH(4, 16); }
+  if (NVG == 4 && unroll_ok && kt == 64) { PVW_GEMM_LAUNCH(4, 8); }
+  else if (NVG == 4 && unroll_ok && kt == 128) { PVW_GEMM_LAUNCH(4, 16); }
   else switch (NVG) {
     case 1: PVW_GEMM_LAUNCH(1, 0); break;
     case 2: PVW_GEMM_LAUNCH(2, 0); break;

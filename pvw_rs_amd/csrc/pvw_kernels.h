@@ -190,14 +190,19 @@ inline size_t xm_words(u32 rows, u32 k, u32 L, u32 ell) {
          ((k + 3) / 4) * 128;
 }
 inline size_t yd_bytes(u32 nv, u32 k, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) * L * ell * ((k + 3) / 4) * 1024; }
+// K tiles (32 contraction rows each) of the digit GEMM.  bytes = 8: a tile is 4 consecutive j x the 8 bytes of the matrix
+// element.  bytes = 7 (every modulus below 2^56, k a multiple of 64): byte 7 of every element is zero and is left out of
+// the contraction -- a tile is one byte position a < 7 of 32 consecutive j, 7 tiles per 32 j instead of 8 (gemm7_ok).
+inline u32 gemm_ktiles(u32 k, u32 bytes) { return bytes == 7 ? 7 * (k / 32) : (k + 3) / 4; }
+inline bool gemm7_ok(u32 max_q_bits, u32 k) { return max_q_bits <= 56 && k % 64 == 0 && k >= 64; }
 inline size_t sy_bytes(u32 nv, u32 L, u32 ell) { return (size_t)((nv + 3) / 4) * L * ell * 32 * sizeof(int); }
-hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s);
+hipError_t launch_mftile(const u64* src, bool src_is_tiled, u64* XM, u32 rows, u32 k, u32 L, u32 ell, hipStream_t s, u32 bytes = 8);
 // small coefficients [row][j][l] -> NTT -> MFMA-tiled raw operand in one pass (l <= 32); padding included
 hipError_t launch_shat_mftile(const i64* coeffs, u64* XM, u32 rows, u32 k, u32 L, u32 ell, const DevTables& t, hipStream_t s);
 // element j of vector v at (limb, slot): vhat[v * vstride + limb * lstride + j * jstride + slot];
 // lstride = jstride = 0 selects the r-hat layout [limb][j][slot] (lstride = k * l, jstride = l)
 hipError_t launch_vec_digits(const u64* vhat, size_t vstride, signed char* YD, int* SY, u32 nv, u32 k, u32 L, u32 ell,
-                             const DevTables& t, hipStream_t s, size_t lstride = 0, size_t jstride = 0);
+                             const DevTables& t, hipStream_t s, size_t lstride = 0, size_t jstride = 0, u32 bytes = 8);
 // nv may exceed 16: batches of 16 vectors then run as extra workgroups of ONE launch (adjacent in dispatch
 // order, so they share the streamed matrix tiles through L2); tmp must hold ceil(nv/16) batches.
 // es_a / es_b != NULL (l <= 32): that section's finish pass adds an error term it draws or reads itself, plus the
@@ -217,7 +222,7 @@ struct GemmErrSource {
 };
 hipError_t launch_gemm_digits(const GemmSection& a, const GemmSection& b, const signed char* YD, const int* SY,
                               const DevTables& t, u32 k, u32 L, u32 ell, u32 nv, size_t ostride_a, size_t ostride_b,
-                              hipStream_t s, const GemmErrSource* es_a = nullptr, const GemmErrSource* es_b = nullptr);
+                              hipStream_t s, const GemmErrSource* es_a = nullptr, const GemmErrSource* es_b = nullptr, u32 bytes = 8);
 // read-only probe: every wave streams `tiles` consecutive 1-KiB tiles (16 in flight), grid as mac_rows
 #if PVW_TUNING
 // time stamps (100 MHz ticks, [2b] start / [2b+1] end) and HW_ID words of the workgroups of the last stamped mac_rows launch

@@ -584,7 +584,26 @@ def multi_dealer_case(D):
 ])
 def test_digit_gemm_multi_dealer_equals_separate_encrypts(n, k, l, L, D):
     # >= 3 dealers take the matrix-core path (gemm_digits_kernel): i8 MFMA over byte-folded operands
-    moduli = M.bench_moduli(L) if l <= 32 else primes_1mod(128, L)
+    digit_gemm_case(n, k, l, M.bench_moduli(L) if l <= 32 else primes_1mod(128, L), D)
+
+
+@pytest.mark.parametrize("n,k,l,L,D", [
+    (37, 64, 8, 4, 5),        # the smallest k of the 7-byte form (14 K tiles), one partial vector group, ragged rows
+    (9, 256, 8, 2, 17),       # 56 K tiles, one full batch + one dealer: the wide form
+    (70, 128, 8, 3, 33),      # three batches in one launch
+    (10, 64, 16, 4, 21),      # l = 16
+    (20, 576, 8, 2, 40),      # k > 512: unbiased integer recombination
+    (5, 1024, 8, 4, 9),       # the reference's own 128-bit set (k = 1024): 224 K tiles, rolled chunk loop
+])
+def test_digit_gemm_seven_byte_contraction(n, k, l, L, D):
+    # every modulus below 2^56 and k a multiple of 64: byte 7 of every matrix element is zero and is left out of the
+    # contraction (gemm_ktiles: 7 K tiles per 32 terms instead of 8; mftile7_kernel / vec_digits7_kernel) -- the reference's
+    # own 56-bit chain (examples/pvw_valid_dec.rs:40-45) against separate encrypts and the C restatement
+    digit_gemm_case(n, k, l, EXAMPLE_MODULI[:L], D)
+
+
+def digit_gemm_case(n, k, l, moduli, D):
+    L = len(moduli)
     p = build_params(n, k, l, moduli)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
     gpk.fill_uniform(SEED)
@@ -616,7 +635,17 @@ def test_digit_gemm_extreme_matrix_bytes_against_c_oracle(n, k, l, L, D):
     # accumulators in f64 (exact while |half-sum| < 2^51, i.e. k <= 512): matrices made of the byte patterns that
     # push the partial sums to their extremes -- all bytes 0x00 (-128 after the offset), q - 1 and 0x..ffff (+127),
     # 0x80.. (0), alternating -- must still give the oracle's ciphertexts (crs.rs:188-201, encryption.rs:177-200)
-    moduli = M.bench_moduli(L)
+    digit_gemm_extreme_case(n, k, l, M.bench_moduli(L), D)
+
+
+@pytest.mark.parametrize("n,k,l,L,D", [(64, 256, 8, 2, 20), (40, 512, 8, 2, 17), (33, 512, 16, 2, 18)])
+def test_digit_gemm_seven_byte_extreme_matrix_bytes(n, k, l, L, D):
+    # the same patterns (cut to residues below the 56-bit moduli) through the 7-byte contraction
+    digit_gemm_extreme_case(n, k, l, EXAMPLE_MODULI[:L], D)
+
+
+def digit_gemm_extreme_case(n, k, l, moduli, D):
+    L = len(moduli)
     p = build_params(n, k, l, moduli)
     rng = np.random.default_rng(k + l)
     q = np.array(moduli, dtype=np.uint64)[None, None, :, None]
@@ -632,7 +661,8 @@ def test_digit_gemm_extreme_matrix_bytes_against_c_oracle(n, k, l, L, D):
                 m[i] = np.uint64(pats[(i // 3 + i) % len(pats)])
         m[0] = 0
         m[1 % rows] = np.uint64(0xFFFFFFFFFFFFFFFF)
-        return np.minimum(m % (np.uint64(1) << np.uint64(61)), q - np.uint64(1))   # residues below q with the byte patterns intact
+        bits = np.uint64(max(moduli).bit_length())
+        return np.minimum(m % (np.uint64(1) << bits), q - np.uint64(1))   # residues below q with the byte patterns intact
 
     a_hat, b_hat = patterned(k), patterned(n)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.from_polynomials(p, a_hat, P.REPR_NTT))

@@ -156,3 +156,11 @@ def test_digit_gemm_round1_form_agrees(monkeypatch):
     monkeypatch.setenv("PVW_GEMM_WIDE", "0")
     T.test_digit_gemm_multi_dealer_equals_separate_encrypts(100, 256, 8, 3, 40)
     T.test_digit_gemm_multi_dealer_equals_separate_encrypts(40, 512, 16, 2, 17)
+
+
+@pytest.mark.parametrize("n,k,l,L,D", [(37, 64, 8, 4, 5), (70, 128, 8, 3, 33)])
+def test_digit_gemm_eight_byte_contraction_on_short_moduli(n, k, l, L, D, monkeypatch):
+    # PVW_GEMM_BYTES=8: moduli below 2^56 through the general 8-byte contraction (what ran before the 7-byte form existed)
+    from _util import EXAMPLE_MODULI
+    monkeypatch.setenv("PVW_GEMM_BYTES", "8")
+    T.digit_gemm_case(n, k, l, EXAMPLE_MODULI[:L], D)

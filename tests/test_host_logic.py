@@ -45,7 +45,7 @@ def test_tuning_library_is_a_superset_and_the_shipped_one_has_no_switches():
         return subprocess.run(["strings", "-a", path], capture_output=True, text=True, check=True).stdout
     def undefined(path):
         return subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
-    switches = ("PVW_GEMM_ZERO_OPERANDS", "PVW_DECODE_TIMING", "PVW_DECODE_SMALL", "PVW_MAC_VARIANT", "PVW_MAC_PACKED", "PVW_MAC_COMPACT", "PVW_DEC_VARIANT",
+    switches = ("PVW_GEMM_ZERO_OPERANDS", "PVW_DECODE_TIMING", "PVW_DECODE_SMALL", "PVW_GEMM_BYTES", "PVW_MAC_VARIANT", "PVW_MAC_PACKED", "PVW_MAC_COMPACT", "PVW_DEC_VARIANT",
                 "PVW_GEMM_MIN_DEALERS", "PVW_KEYGEN_SWAP")
     s_def, s_tun = strings(_ffi.LIB_PATH), strings(_ffi.LIB_TUNING_PATH)
     for name in switches:
