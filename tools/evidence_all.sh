@@ -12,6 +12,7 @@ run c4shard --config c4shard --steps 50 --warmup 5 --no-cpu
 run ref128x --config ref128x --steps 100 --warmup 10 --no-cpu
 PVW_MAC_PACKED=0 run ref128x_unpacked --config ref128x --steps 100 --warmup 10 --no-cpu --tuning-library
 run multi64 --dealers 64 --steps 20 --warmup 3 --no-cpu
+run ref128x_multi64 --config ref128x --dealers 64 --steps 20 --warmup 3 --no-cpu
 run keygen --path keygen --steps 20 --warmup 3 --no-cpu
 run decrypt_c5shard --path decrypt --config c5shard --steps 200 --warmup 20
 run decrypt_c5full --path decrypt --config c5full --steps 20 --warmup 3
