@@ -714,8 +714,20 @@ def test_multi_dealer_encrypt_l16_and_sharded():
         assert not part[d].c1[:2].any() and not part[d].c2[8:].any()
 
 
+def mixed_width_moduli(count):
+    # alternating 61-bit and 40-bit primes (= 1 mod 64): an earlier modulus more than twice a later one, so a mixed-radix
+    # digit of the decode's short cut does not reduce to the next modulus with one subtraction
+    wide, narrow = primes_1mod(64, (count + 1) // 2), primes_1mod(64, count // 2, top=1 << 40)
+    return [wide[i // 2] if i % 2 == 0 else narrow[i // 2] for i in range(count)]
+
+
+# which of the decode's short cuts the sets below reach (DecodeTables: gar_n / sc_on / hs_on): one modulus: none; the 36/37-bit
+# test chain: candidates only (Q below 194 bits); the bench chains at l = 8 / 16 (Delta of 130 bits, three-word 2 Delta)
+# and 17 limbs at l = 16 (Delta of 65 bits, two words): all of them; l = 64 over 5 limbs (Delta of 5 bits, one word):
+# the chain at once but noise_{l-1} from the lifted Horner value; mixed widths: all, with full reductions between the digits
 @pytest.mark.parametrize("l,moduli", [(8, [0xFFFFEE001]), (8, TEST_MODULI), (32, TEST_MODULI), (8, M.bench_moduli(17)),
-                                      (16, M.bench_moduli(34)), (64, primes_1mod(128, 5))])
+                                      (16, M.bench_moduli(34)), (64, primes_1mod(128, 5)), (16, M.bench_moduli(17)),
+                                      (8, mixed_width_moduli(12)), (8, mixed_width_moduli(5))])
 def test_device_decode_matches_model(l, moduli):
     device_decode_case(l, moduli, lambda variant: None, (0,))
 
