@@ -11,14 +11,16 @@
 namespace pvw {
 
 // ------------------------------------------------------------------------------------
-// decode, wave-cooperative form: ONE WAVE per ciphertext.  A big integer lives one 64-bit word
-// per lane (word w in lane w), an RNS value one limb per lane; every step of pvw_decode.h's
-// algorithm becomes "per-lane column sums + a short cross-lane carry loop":
+// decode, wave-cooperative form.  A big integer lives one 64-bit word per lane (word w in lane w), an RNS value one limb
+// per lane; every step of pvw_decode.h's algorithm becomes "per-lane column sums + a short cross-lane carry loop":
 //   lift      x = sum_i t_i * (Q/q_i) - kq*Q          L broadcast steps, columns of 3 words
-//   to RNS    r_limb = sum_j x_j * 2^(64 j) mod q      W broadcast steps, lazy accumulator
 //   divide    q^ = floor(N * floor(B^(W+1)/d) / B^(W+1)) from the top W+2 columns only, then
 //             at most two corrections against the exact remainder (no digit-serial long division)
 // Needs L <= 64 and W + 2 <= 63 (Q up to ~3900 bits); otherwise launch_decode uses decode_kernel.
+// That is the GENERAL path.  In front of it sit short cuts for what a decrypt actually produces -- values that are
+// noise-sized against Q -- each a guess from a few residues that is proven on every limb before it is used
+// (small_candidates / small_confirm, small_top, small_chain below); an input for which a proof fails takes the general
+// path, so the result is the same for every input.
 // ------------------------------------------------------------------------------------
 struct WaveBN {
   u64 x;   // this lane's word
@@ -473,17 +475,19 @@ __device__ __forceinline__ void wave_divmod2(const WaveDecodeCtx& c, u64 n, cons
 
 // decode, lifted-chain form: WPC waves per ciphertext, CPW ciphertexts per workgroup.
 // The reference's chain noise_i = round((noise_{i+1} - tmp_i) / Delta) (decryption.rs:44-48) is exact
-// integer arithmetic mod Q, so it can be carried in big-integer form throughout: the l+1 CRT lifts it
-// needs (tmp_0..tmp_{l-2}, the Horner value, z_0) do not depend on the chain and are spread over the
-// WPC waves; after one barrier wave 0 walks the chain with one short-divisor division per step and NO
-// conversion back to RNS.  Serial big steps per ciphertext: l divisions (instead of l+1 lifts +
-// l divisions + l RNS conversions of the first, one-wave-per-ciphertext form: 0.20 -> 0.10 ms per 1024 ciphertexts at
-// 2074-bit Q; two or eight waves per ciphertext for the lifts measured no better).
+// integer arithmetic mod Q, so it can be carried in big-integer form throughout: the inputs it needs
+// (tmp_0..tmp_{l-2}, z_0, the Horner value) do not depend on the chain and are settled by the WPC waves
+// (drawn from a counter: a confirmed short-cut candidate or a full CRT lift each); after a barrier wave 0
+// takes noise_{l-1} and the chain -- at once on noise-sized values (small_chain), else one short-divisor
+// division per step on W-word integers -- with NO conversion back to RNS.
+// Timings per 1024 ciphertexts at 2074-bit Q: the first, one-wave-per-ciphertext form with lifts, divisions and RNS
+// conversions in series 0.20 ms; lifts spread over four waves 0.10-0.12 ms (two or eight waves no better); with the
+// short cuts 0.02 ms on well-formed ciphertexts, 0.10 ms on uniform residues.
 // blk = the workgroup's index among the decode workgroups; dws = its dynamic LDS.
-// (Measured and dropped in round 3: the inverse transform of the noisy polynomial folded in here -- one limb per lane of the
-// ciphertext's first wave -- instead of the INTT launch between the inner products and the decode.  The step did not
-// move (499.8 vs 497 us at the config-5 shard: the decode grew by what the launch had cost) and the extra registers
-// ended the co-residency with decrypt_mac that the overlapped batch path lives on (config 5 in full: 4.05 vs 3.10 ms).)
+// (Round 3, first attempt at the inverse transform of decrypt inside this kernel: one limb per lane of the
+// ciphertext's first wave -- the step did not move and the extra registers ended the co-residency with decrypt_mac that
+// the overlapped batch path lives on (config 5 in full: 4.05 vs 3.10 ms).  What ships is stage_inverse in an instance of
+// its own, used only where the decode does not share the chip: pvw_decode_kernels.hip.)
 // tables of the inverse transform when the decode does it itself (itw == nullptr: the input is in power basis already)
 struct InverseTables {
   const u64* itw;    // [L][l]  psi^-bitrev(i)
