@@ -325,33 +325,55 @@ __global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restr
 }
 
 // decrypt_finish: noisy[d] = INTT( sum_r partial[r][d] - c2col[d] )   (decryption.rs:268-274 and the
-// change_representation(PowerBasis) of :116), one thread per (dealer, limb): the range sums of a split decrypt_mac
-// are added up where the inverse transform reads them anyway
+// change_representation(PowerBasis) of :116): the range sums of a split decrypt_mac are added up where the inverse
+// transform reads them anyway.  ELL/2 threads per (dealer, limb): thread b adds up slots 2b, 2b+1 of the ranges,
+// subtracts c2 and takes one butterfly per stage of ntt_inverse through LDS (the ELL/2 threads are consecutive and share
+// a wave, whose LDS accesses execute in order: no barrier).  A split decrypt is a SMALL batch -- one decrypt_party_value
+// is 34 such polynomials -- and with one thread per polynomial this pass was 17.6 us of pure latency at the config-5
+// geometry.
 template <int ELL>
-__global__ __launch_bounds__(64) void decrypt_finish_kernel(const u64* __restrict__ partial, u32 nsplit,
-                                                             const u64* __restrict__ c2col, u64* __restrict__ noisy,
-                                                             u32 dealers, u32 L, DevTables t) {
-  const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= dealers * L) return;
-  const u32 limb = tid % L;
+__global__ __launch_bounds__(256) void decrypt_finish_kernel(const u64* __restrict__ partial, u32 nsplit,
+                                                              const u64* __restrict__ c2col, u64* __restrict__ noisy,
+                                                              u32 dealers, u32 L, DevTables t) {
+  constexpr u32 H = ELL / 2;
+  __shared__ u64 buf[256 / H * ELL];
+  const u32 tid = blockIdx.x * 256 + threadIdx.x;
+  const u32 pl = tid / H, b = tid % H;                   // (dealer, limb) pair; butterfly
+  const bool on = pl < dealers * L;
+  const u32 limb = on ? pl % L : 0;
   const Mod m = t.mods[limb];
-  const size_t o = (size_t)tid * ELL, plane = (size_t)dealers * L * ELL;
-  u64 a[ELL];
-#pragma unroll
-  for (int s = 0; s < ELL; s += 2) {
-    const v2u64 c2 = *reinterpret_cast<const v2u64*>(c2col + o + s);
-    v2u64 acc = *reinterpret_cast<const v2u64*>(partial + o + s);
+  const size_t o = (size_t)(on ? pl : 0) * ELL + 2 * b, plane = (size_t)dealers * L * ELL;
+  u64* a = buf + (threadIdx.x / H) * ELL;
+  if (on) {
+    const v2u64 c2 = *reinterpret_cast<const v2u64*>(c2col + o);
+    v2u64 acc = *reinterpret_cast<const v2u64*>(partial + o);
     for (u32 r = 1; r < nsplit; ++r) {
-      const v2u64 p = *reinterpret_cast<const v2u64*>(partial + r * plane + o + s);
+      const v2u64 p = *reinterpret_cast<const v2u64*>(partial + r * plane + o);
       acc.x = addmod(acc.x, p.x, m.q);
       acc.y = addmod(acc.y, p.y, m.q);
     }
-    a[s] = submod(acc.x, c2.x, m.q);
-    a[s + 1] = submod(acc.y, c2.y, m.q);
+    a[2 * b] = submod(acc.x, c2.x, m.q);
+    a[2 * b + 1] = submod(acc.y, c2.y, m.q);
   }
-  ntt_inverse<ELL>(a, t.itw + (size_t)limb * ELL, t.itwp + (size_t)limb * ELL, t.linv[limb], t.linvp[limb], m);
+  __builtin_amdgcn_wave_barrier();
+  const u64* tw = t.itw + (size_t)limb * ELL;
+  const u64* twp = t.itwp + (size_t)limb * ELL;
+  u32 step = 1;
 #pragma unroll
-  for (int s = 0; s < ELL; s += 2) *reinterpret_cast<v2u64*>(noisy + o + s) = (v2u64){a[s], a[s + 1]};
+  for (u32 mm = H; mm >= 1; mm >>= 1) {
+    const u32 i = b / step, j = 2 * i * step + (b % step);
+    if (on) {
+      const u64 u = a[j], v = a[j + step];
+      a[j] = addmod(u, v, m.q);
+      a[j + step] = mulmod_shoup(submod(u, v, m.q), tw[mm + i], twp[mm + i], m.q);
+    }
+    __builtin_amdgcn_wave_barrier();
+    step <<= 1;
+  }
+  if (on) {
+    const u64 li = t.linv[limb], lip = t.linvp[limb];
+    *reinterpret_cast<v2u64*>(noisy + o) = (v2u64){mulmod_shoup(a[2 * b], li, lip, m.q), mulmod_shoup(a[2 * b + 1], li, lip, m.q)};
+  }
 }
 // how many ranges of j a decrypt over `dealers` ciphertexts is cut into (1 = no split): enough workgroups to put one
 // on every CU when the batch alone does not, never ranges shorter than 64 terms
@@ -374,8 +396,8 @@ u32 decrypt_split(u32 k, u32 L, u32 ell, size_t dealers) {
 hipError_t launch_decrypt_finish(const u64* partial, u32 nsplit, const u64* c2col, u64* noisy, const DevTables& t, u32 L, u32 ell,
                                  size_t dealers, hipStream_t s) {
   if (dealers == 0) return hipSuccess;
-  const u32 threads = (u32)dealers * L;
-  PVW_DISPATCH_ELL(ell, decrypt_finish_kernel<E><<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(partial, nsplit, c2col, noisy, (u32)dealers, L, t));
+  const size_t threads = dealers * L * (ell / 2);
+  PVW_DISPATCH_ELL(ell, decrypt_finish_kernel<E><<<dim3((u32)((threads + 255) / 256)), dim3(256), 0, s>>>(partial, nsplit, c2col, noisy, (u32)dealers, L, t));
   return hipGetLastError();
 }
 
