@@ -1,6 +1,8 @@
 // pvw_poly.hip -- the small-polynomial kernels of the PVW path on gfx950: signed coefficients -> RNS -> l-point NTT
 // (prep, prologue), in-place (I)NTT, API layout <-> tiled matrix, the samplers.  All O(n + k) polynomials per call:
-// launch-latency sized, one thread per (polynomial, limb) with the transform fully unrolled in registers.
+// launch-latency sized.  Where the transform comes with other per-polynomial work (sampling, tiling) it is one thread per
+// (polynomial, limb), fully unrolled in registers; the plain transforms (ntt_kernel, prep_coop_kernel) take l/2 threads
+// per polynomial, one butterfly per thread and stage through LDS.
 #include <hip/hip_runtime.h>
 
 #include "pvw_arith.h"
@@ -97,10 +99,11 @@ __global__ __launch_bounds__(256) void transpose_polys_kernel(const u64* __restr
   dst[((size_t)c * k + j) * words + x] = src[idx];
 }
 
-// in-place change_representation on [count][L][l] polynomials
+// in-place change_representation on [count][L][l] polynomials, one thread per polynomial, fully unrolled in registers:
+// the form for large batches (fewest instructions per polynomial)
 template <int ELL>
-__global__ __launch_bounds__(64) void ntt_kernel(u64* __restrict__ polys, u32 count, u32 L,
-                                                  u32 inverse, DevTables t) {
+__global__ __launch_bounds__(64) void ntt_poly_kernel(u64* __restrict__ polys, u32 count, u32 L,
+                                                       u32 inverse, DevTables t) {
   const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= count * L) return;
   const u32 limb = tid % L;
@@ -118,6 +121,69 @@ __global__ __launch_bounds__(64) void ntt_kernel(u64* __restrict__ polys, u32 co
 #pragma unroll
   for (int s = 0; s < ELL; s += 2)
     *reinterpret_cast<v2u64*>(p + s) = (v2u64){a[s], a[s + 1]};
+}
+
+// the same for small batches (a decrypt's D polynomials, an encrypt's n + k): ELL/2 threads per polynomial, thread b brings in and
+// takes out slots 2b, 2b+1 (16 contiguous bytes: a wave moves whole lines) and takes one butterfly per stage of
+// ntt_forward / ntt_inverse through LDS; the ELL/2 threads are consecutive and share a wave, whose LDS accesses execute in
+// order, so the stages need no barrier.  A batch this small is pure latency with one thread per polynomial (decrypt_finish:
+// 17.6 -> 7 us); a large one is better off with fewer instructions per polynomial (config 5 in full, 8192 x 34
+// polynomials per step beside the inner products: 145 us of transform time against 183 us in this form).
+template <int ELL>
+__global__ __launch_bounds__(256) void ntt_kernel(u64* __restrict__ polys, u32 count, u32 L,
+                                                   u32 inverse, DevTables t) {
+  constexpr u32 H = ELL / 2;
+  __shared__ u64 buf[256 / H * ELL];
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t pl = tid / H;
+  const u32 b = (u32)(tid % H);
+  const bool on = pl < (size_t)count * L;
+  const u32 limb = on ? (u32)(pl % L) : 0;
+  const Mod m = t.mods[limb];
+  u64* p = polys + (on ? pl : 0) * ELL + 2 * b;
+  u64* a = buf + (threadIdx.x / H) * ELL;
+  if (on) {
+    const v2u64 v = *reinterpret_cast<const v2u64*>(p);
+    a[2 * b] = v.x;
+    a[2 * b + 1] = v.y;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (inverse) {
+    const u64* tw = t.itw + (size_t)limb * ELL;
+    const u64* twp = t.itwp + (size_t)limb * ELL;
+    u32 step = 1;
+#pragma unroll
+    for (u32 mm = H; mm >= 1; mm >>= 1) {
+      const u32 i = b / step, j = 2 * i * step + (b % step);
+      if (on) {
+        const u64 u = a[j], v = a[j + step];
+        a[j] = addmod(u, v, m.q);
+        a[j + step] = mulmod_shoup(submod(u, v, m.q), tw[mm + i], twp[mm + i], m.q);
+      }
+      __builtin_amdgcn_wave_barrier();
+      step <<= 1;
+    }
+    if (on) {
+      const u64 li = t.linv[limb], lip = t.linvp[limb];
+      *reinterpret_cast<v2u64*>(p) = (v2u64){mulmod_shoup(a[2 * b], li, lip, m.q), mulmod_shoup(a[2 * b + 1], li, lip, m.q)};
+    }
+  } else {
+    const u64* tw = t.tw + (size_t)limb * ELL;
+    const u64* twp = t.twp + (size_t)limb * ELL;
+    u32 step = ELL;
+#pragma unroll
+    for (u32 mm = 1; mm < ELL; mm <<= 1) {
+      step >>= 1;
+      const u32 i = b / step, j = 2 * i * step + (b % step);
+      if (on) {
+        const u64 u = a[j], v = mulmod_shoup(a[j + step], tw[mm + i], twp[mm + i], m.q);
+        a[j] = addmod(u, v, m.q);
+        a[j + step] = submod(u, v, m.q);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (on) *reinterpret_cast<v2u64*>(p) = (v2u64){a[2 * b], a[2 * b + 1]};
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -416,9 +482,14 @@ hipError_t launch_ntt(u64* polys, size_t count, bool inverse, const DevTables& t
   const size_t step = (size_t)1 << 24;
   for (size_t off = 0; off < count; off += step) {
     const u32 cnt = (u32)((count - off) < step ? (count - off) : step);
-    const u32 threads = cnt * L;
     u64* p = polys + off * L * ell;
-    PVW_DISPATCH_ELL(ell, ntt_kernel<E><<<dim3((threads + 63) / 64), dim3(64), 0, s>>>(p, cnt, L, inverse ? 1u : 0u, t));
+    if ((size_t)cnt * L > 8192) {
+      const u32 polys_l = cnt * L;
+      PVW_DISPATCH_ELL(ell, ntt_poly_kernel<E><<<dim3((polys_l + 63) / 64), dim3(64), 0, s>>>(p, cnt, L, inverse ? 1u : 0u, t));
+      continue;
+    }
+    const size_t threads = (size_t)cnt * L * (ell / 2);
+    PVW_DISPATCH_ELL(ell, ntt_kernel<E><<<dim3((u32)((threads + 255) / 256)), dim3(256), 0, s>>>(p, cnt, L, inverse ? 1u : 0u, t));
   }
   return hipGetLastError();
 }
