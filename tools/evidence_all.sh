@@ -14,7 +14,10 @@ PVW_MAC_PACKED=0 run ref128x_unpacked --config ref128x --steps 100 --warmup 10 -
 run multi64 --dealers 64 --steps 20 --warmup 3 --no-cpu
 run ref128x_multi64 --config ref128x --dealers 64 --steps 20 --warmup 3 --no-cpu
 run keygen --path keygen --steps 20 --warmup 3 --no-cpu
+bash tools/profile_all.sh ${tag}_c5shard c5shard --path decrypt --config c5shard --no-worst-case > gpurun_out/${tag}_c5shard_profile.log 2>&1 || echo "c5shard profile failed"
+cp profiles/${tag}_c5shard_summary.json profiles/${tag}_c5shard_kernel_stats.csv gpurun_out/ 2>/dev/null || true
 run decrypt_c5shard --path decrypt --config c5shard --steps 200 --warmup 20
+run decrypt_c5one --path decrypt --config c5one --steps 300 --warmup 30
 run decrypt_c5full --path decrypt --config c5full --steps 20 --warmup 3
 run decrypt_d3 --path decrypt --config d3 --steps 200 --warmup 20
 python3 - <<PY
