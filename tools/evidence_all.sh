@@ -9,6 +9,7 @@ bash tools/evidence.sh $tag
 run() { name=$1; shift; timeout -k 10 400 python3 bench.py "$@" > gpurun_out/${tag}_${name}_bench.json 2> gpurun_out/${tag}_${name}_bench.err; echo "$name done"; }
 run c2 --config c2 --steps 200 --warmup 20 --no-cpu
 run c4shard --config c4shard --steps 50 --warmup 5 --no-cpu
+run c4full --config c4full --steps 10 --warmup 2 --no-cpu
 run ref128x --config ref128x --steps 100 --warmup 10 --no-cpu
 PVW_MAC_PACKED=0 run ref128x_unpacked --config ref128x --steps 100 --warmup 10 --no-cpu --tuning-library
 run multi64 --dealers 64 --steps 20 --warmup 3 --no-cpu
