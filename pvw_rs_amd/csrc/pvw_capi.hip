@@ -1949,7 +1949,7 @@ int32_t pvw_decode_device(pvw_ctx* c, const uint64_t* d_noisy, size_t count, uin
 // the pass that adds them up (decrypt_finish) does it; without, the consumer does -- the decode kernel itself
 // (launch_decode with the transform tables) or launch_ntt.
 static int32_t decrypt_mac_only(pvw_ctx* c, Workspace* w, const u64* d_c1s, const u64* d_c2col, size_t D, u64* d_noisy,
-                                hipStream_t s, bool* ntt_domain) {
+                                hipStream_t s, bool* ntt_domain, bool alone = true) {
   const u32 k = c->k, l = c->l, L = c->L;
   const u32 ns = decrypt_split(k, L, l, D);
   if (ns > 1) {
@@ -1962,7 +1962,7 @@ static int32_t decrypt_mac_only(pvw_ctx* c, Workspace* w, const u64* d_c1s, cons
   }
   {
     ProfScope ps(c, "decrypt_mac", s);
-    PVW_HIP(launch_decrypt_mac(d_c1s, w->rhat, d_c2col, d_noisy, c->dt, k, L, l, D, s, w->dpart, ns));
+    PVW_HIP(launch_decrypt_mac(d_c1s, w->rhat, d_c2col, d_noisy, c->dt, k, L, l, D, s, w->dpart, ns, alone));
   }
   *ntt_domain = ns <= 1;
   if (ns > 1) {
@@ -2066,7 +2066,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
     const size_t d0 = i * chunk, cnt = (D - d0) < chunk ? (D - d0) : chunk;
     u64* nz = d_noisy + d0 * P;
     bool ntt_domain = false;
-    PVW_TRY(decrypt_mac_only(c, w, d_c1s + d0 * k * P, d_c2col + d0 * P, cnt, nz, s, &ntt_domain));             // decryption.rs:257-274
+    PVW_TRY(decrypt_mac_only(c, w, d_c1s + d0 * k * P, d_c2col + d0 * P, cnt, nz, s, &ntt_domain, !overlap));   // decryption.rs:257-274
     hipStream_t ds = s;
     if (overlap) {
       PVW_HIP(hipEventRecord(w->events[i], s));

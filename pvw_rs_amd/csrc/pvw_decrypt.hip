@@ -206,7 +206,7 @@ __global__ __launch_bounds__(MAXT) void decrypt_mac_grouped_kernel(const u64* __
 // (88 VGPRs is a budget, not an accident: 13 of these waves and the 8 waves of a decode workgroup share a CU when
 // pvw_decrypt_batch_device overlaps the two; prefetching c2 at the top costs 12 registers, gains 1.5 % alone and
 // loses 20 % overlapped.)
-template <int DG, int UJ>
+template <int DG, int UJ, int SB = 0>
 __global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restrict__ c1s,
                                                                const u64* __restrict__ shat,
                                                                const u64* __restrict__ c2col,
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restr
 #pragma unroll
         for (int dd = 0; dd < DG; ++dd) x[u][dd] = __builtin_nontemporal_load(cp[dd] + (size_t)(j + u * jstep) * pairs);
       }
+      if (SB) __builtin_amdgcn_sched_barrier(0);                   // every load of the group issued before its first MAC
 #pragma unroll
       for (int u = 0; u < UJ; ++u)
 #pragma unroll
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(1024) void decrypt_mac_fw_kernel(const u64* __restr
           acc_mac_dev(a0[dd], x[u][dd].x, y[u].x);
           acc_mac_dev(a1[dd], x[u][dd].y, y[u].y);
         }
+      if (SB) __builtin_amdgcn_sched_barrier(0);
     }
     for (; j < k; j += jstep) {
       v2u64 y0 = sp[(size_t)j * pairs];
@@ -403,7 +405,7 @@ hipError_t launch_decrypt_finish(const u64* partial, u32 nsplit, const u64* c2co
 
 hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col, u64* noisy,
                               const DevTables& t, u32 k, u32 L, u32 ell, size_t dealers,
-                              hipStream_t s, u64* partial, u32 nsplit) {
+                              hipStream_t s, u64* partial, u32 nsplit, bool alone) {
   if (dealers == 0) return hipSuccess;
   if (nsplit == 0 || !partial) nsplit = 1;
   const u32 pairs = L * ell / 2;
@@ -453,8 +455,16 @@ hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col,
       const u32 thr = waves * 64;
       // two dealers per workgroup, four j-steps in flight (one / three dealers and 2 / 8 steps were measured: r01d_decrypt_sweep;
       // again in round 3 with the register budget varied as well, profiles/r03_decrypt_mac_shapes.txt: 425-735 us against 362-369)
-      decrypt_mac_fw_kernel<2, 4><<<dim3((u32)((dealers + 1) / 2), nsplit), dim3(thr), (size_t)2 * thr * sizeof(v2u64), s>>>(
-          c1s, shat, c2col, noisy, t.mods, k, ell, pairs, FW, cfull, remp, crem, (u32)dealers, partial);
+      // Left to itself the compiler sinks each j-step's three loads down to their MACs (3 KiB in flight per wave, 88 registers).
+      // SB = 1 keeps the group's twelve loads together in front of its MACs (124 registers): 362 vs 370 us at the config-5
+      // shard.  Not when a decode is to share the CUs with this launch (the overlapped batch path): 13 of these waves and the
+      // 8 of a decode workgroup fit a CU only at 88 registers.
+      if (alone)
+        decrypt_mac_fw_kernel<2, 4, 1><<<dim3((u32)((dealers + 1) / 2), nsplit), dim3(thr), (size_t)2 * thr * sizeof(v2u64), s>>>(
+            c1s, shat, c2col, noisy, t.mods, k, ell, pairs, FW, cfull, remp, crem, (u32)dealers, partial);
+      else
+        decrypt_mac_fw_kernel<2, 4><<<dim3((u32)((dealers + 1) / 2), nsplit), dim3(thr), (size_t)2 * thr * sizeof(v2u64), s>>>(
+            c1s, shat, c2col, noisy, t.mods, k, ell, pairs, FW, cfull, remp, crem, (u32)dealers, partial);
       return hipGetLastError();
     }
   }

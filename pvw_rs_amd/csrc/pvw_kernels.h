@@ -151,10 +151,12 @@ hipError_t launch_gaussian(i64* out, const ChaChaKey& key, u32 index0, u32 count
 // nsplit > 1 (from decrypt_split; `partial` then holds nsplit x dealers polynomials): the k terms are cut into nsplit
 // ranges whose sums go to `partial`; launch_decrypt_finish adds them up, subtracts c2 and transforms back.
 // nsplit <= 1: noisy = <s-hat, c1> - c2 in the NTT domain, as before (follow with launch_ntt(inverse)).
+// alone = false: another kernel (the decode of the previous chunk) is meant to share the CUs with this launch: the
+// register-lean instance is used (pvw_decrypt.hip).
 u32 decrypt_split(u32 k, u32 L, u32 ell, size_t dealers);
 hipError_t launch_decrypt_mac(const u64* c1s, const u64* shat, const u64* c2col, u64* noisy,
                               const DevTables& t, u32 k, u32 L, u32 ell, size_t dealers,
-                              hipStream_t s, u64* partial = nullptr, u32 nsplit = 1);
+                              hipStream_t s, u64* partial = nullptr, u32 nsplit = 1, bool alone = true);
 hipError_t launch_decrypt_finish(const u64* partial, u32 nsplit, const u64* c2col, u64* noisy, const DevTables& t, u32 L, u32 ell,
                                  size_t dealers, hipStream_t s);
 
