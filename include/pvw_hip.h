@@ -271,6 +271,12 @@ PVW_API int32_t pvw_selftest_secret_residue(pvw_ctx* ctx, uint64_t* nonzero_word
  * pinned against the published SipHash-2-4 vector */
 PVW_API int32_t pvw_selftest_siphash(const uint8_t* msg, size_t len, uint64_t k0, uint64_t k1, int32_t c_rounds,
                                      int32_t d_rounds, uint64_t* out);
+/* SELF-TEST (host only, no GPU): the per-context constants behind the short cuts of the device gadget decode
+ * (decode_scalar_pvw_rns, src/crypto/decryption.rs:10-247: mixed-radix inverses and partial products of the leading
+ * moduli, the normalised 2*Delta with its reciprocal, Delta^(l-1) mod q_i with its inverses) checked against their
+ * defining identities.  info_out[0..3] = leading moduli used (0 = none), whether their mixed-radix digits reduce with one
+ * subtraction, whether the chain runs on short operands, whether noise_{l-1} is proven without the Horner lift. */
+PVW_API int32_t pvw_selftest_decode_tables(const pvw_ctx* ctx, uint32_t info_out[4]);
 /* 1 for the measurement build libpvw_hip_tuning.so (include/pvw_hip_tuning.h: environment-selected kernel
  * schedules, timing ablations, bandwidth probe), 0 for the shipped library, which reads no environment variable */
 PVW_API int32_t pvw_build_is_tuning(void);

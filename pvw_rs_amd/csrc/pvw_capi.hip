@@ -1084,6 +1084,58 @@ int32_t pvw_crs_seed_from_tag(const char* tag, uint8_t seed_out[32]) {
   return PVW_OK;
 }
 
+// SELF-TEST (host only): the constants behind the short cuts of the device decode (DecodeTables::gar / sc / dpm, built in
+// build_decode_tables) against their defining identities, recomputed here with the host big integers.  info_out[0..3] =
+// gar_n, gar_close, sc_on, hs_on -- which short cuts the parameter set reaches.
+int32_t pvw_selftest_decode_tables(const pvw_ctx* c, uint32_t info_out[4]) {
+  if (!c || !info_out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  const DecodeTables& t = c->dec_host;
+  info_out[0] = t.gar_n; info_out[1] = t.gar_close; info_out[2] = t.sc_on; info_out[3] = t.hs_on;
+  auto words = [](const u64* w, size_t n) { return BigInt::from_words(w, n); };
+  if (t.gar_n) {
+    if (t.gar_n < 2 || t.gar_n > 4 || t.gar_n >= c->L) return fail(PVW_ERR_INTERNAL, "decode tables: gar_n out of range");
+    BigInt prod(1);
+    bool close = true;
+    for (u32 j = 0; j <= t.gar_n; ++j) {
+      if (BigInt::cmp(words(t.gar + 32 + 4 * j, 4), prod) != 0) return fail(PVW_ERR_INTERNAL, "decode tables: partial product");
+      if (j == t.gar_n) break;
+      const u64 qj = c->moduli[j];
+      for (u32 i = 0; i < j; ++i) {
+        const u64 inv = t.gar[4 * j + i];
+        if (inv >= qj || mulmod(inv, c->moduli[i] % qj, c->mods[j]) != 1) return fail(PVW_ERR_INTERNAL, "decode tables: mixed-radix inverse");
+        if (t.gar[16 + 4 * j + i] != shoup_precompute(inv, qj)) return fail(PVW_ERR_INTERNAL, "decode tables: Shoup companion");
+        if (c->moduli[i] >= 2 * qj) close = false;
+      }
+      prod = prod * BigInt(qj);
+    }
+    if (BigInt::cmp(words(t.gar + 52, 4), prod.shr(1)) != 0) return fail(PVW_ERR_INTERNAL, "decode tables: half product");
+    if ((t.gar_close != 0) != close) return fail(PVW_ERR_INTERNAL, "decode tables: gar_close");
+  }
+  const BigInt td = c->delta * BigInt(2);
+  if (t.sc_on) {
+    if (!t.gar_n || c->Q.bits() < 194 || td.mag.size() > 3) return fail(PVW_ERR_INTERNAL, "decode tables: sc_on without its conditions");
+    const size_t sh = 192 - td.bits();
+    if (t.sc[4] != sh / 64 || t.sc[5] != sh % 64 || !(t.sc[2] >> 63)) return fail(PVW_ERR_INTERNAL, "decode tables: divisor shift");
+    if (BigInt::cmp(words(t.sc, 3), td.shl(sh)) != 0) return fail(PVW_ERR_INTERNAL, "decode tables: normalised divisor");
+    const BigInt recip = (BigInt(1).shl(128) - BigInt(1)) / BigInt(t.sc[2]) - BigInt(1).shl(64);
+    if (BigInt::cmp(words(t.sc + 3, 1), recip) != 0) return fail(PVW_ERR_INTERNAL, "decode tables: reciprocal");
+    if (BigInt::cmp(words(t.sc + 6, 3), c->delta) != 0) return fail(PVW_ERR_INTERNAL, "decode tables: Delta words");
+  }
+  bool all_inv = true;
+  for (u32 i = 0; i < c->L; ++i) {
+    const u64 q = c->moduli[i], v = c->delta_pow.mod_small(q);
+    if (t.dpm[i] != v || t.dpm[c->L + i] != shoup_precompute(v, q)) return fail(PVW_ERR_INTERNAL, "decode tables: Delta^(l-1) residue");
+    if (!v) { all_inv = false; continue; }
+    const u64 inv = t.dpm[2 * c->L + i];
+    if (mulmod(inv, v, c->mods[i]) != 1 || t.dpm[3 * c->L + i] != shoup_precompute(inv, q)) return fail(PVW_ERR_INTERNAL, "decode tables: Delta^(l-1) inverse");
+  }
+  if (t.hs_on) {
+    const bool room = BigInt::cmp(c->halfQ, c->delta_pow.shl(61) + c->delta) > 0;
+    if (!t.sc_on || !all_inv || !room || c->l < 3 || c->moduli[0] >= (1ULL << 62)) return fail(PVW_ERR_INTERNAL, "decode tables: hs_on without its conditions");
+  }
+  return PVW_OK;
+}
+
 int32_t pvw_build_is_tuning(void) { return PVW_TUNING; }
 
 // SELF-TEST: 64-bit words that are not zero in the regions the last key-bearing call on each pooled workspace

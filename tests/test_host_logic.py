@@ -241,3 +241,33 @@ def test_device_entry_points_fail_loudly_without_gpu():
     assert e.value.variant == "InternalError" and "no CPU fallback" in str(e.value)
     with pytest.raises(P.PvwError):
         p.ntt_forward(np.zeros((1, 3, 8), dtype=np.uint64))
+
+
+def test_decode_short_cut_tables_hold_their_identities():
+    # The short cuts of the device gadget decode (decode_scalar_pvw_rns, decryption.rs:10-247) rest on per-context
+    # constants: mixed-radix inverses and partial products of the leading moduli, the normalised 2*Delta and its
+    # reciprocal, Delta^(l-1) mod q_i and its inverses.  Host-only self-test of their defining identities, and which short
+    # cuts each parameter set reaches: (leading moduli, digits reduce by one subtraction, short chain, proven top noise)
+    import ctypes as C
+    from _util import primes_1mod
+    from pvw_rs_amd import workloads as W
+    lib = _ffi.lib()
+    wide, narrow = primes_1mod(64, 6), primes_1mod(64, 6, top=1 << 40)
+    mixed = [wide[i // 2] if i % 2 == 0 else narrow[i // 2] for i in range(12)]
+    cases = [
+        (8, [0xFFFFEE001], (0, 0, 0, 0)),                     # one modulus: nothing to confirm a candidate against
+        (8, TEST_MODULI, (2, 1, 0, 0)),                       # Q of 109 bits: candidates only
+        (8, W.bench_moduli(17), (3, 1, 1, 1)),                # configs[1..2]: everything
+        (16, W.bench_moduli(34), (3, 1, 1, 1)),               # configs[3..4]
+        (16, W.bench_moduli(17), (2, 1, 1, 1)),               # Delta of 65 bits: a two-word divisor
+        (64, primes_1mod(128, 5), (2, 1, 1, 0)),              # Delta of 5 bits: no room for the proof of noise_{l-1}
+        (8, EXAMPLE_MODULI, (2, 1, 1, 0)),                    # the reference's 4 x 56-bit chain, Delta of 28 bits
+        (8, mixed, (2, 0, 1, 1)),                             # 61- and 40-bit moduli alternating
+    ]
+    for l, moduli, want in cases:
+        p = (P.PvwParametersBuilder().set_parties(3).set_dimension(4).set_l(l).set_moduli(moduli)
+             .set_secret_variance(0.5).set_error_bounds(100, 200).build())
+        info = (C.c_uint32 * 4)()
+        rc = lib.pvw_selftest_decode_tables(p._h, info)
+        assert rc == 0, _ffi.last_error()
+        assert tuple(info) == want, (l, len(moduli), tuple(info))
