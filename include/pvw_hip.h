@@ -271,6 +271,12 @@ PVW_API int32_t pvw_selftest_secret_residue(pvw_ctx* ctx, uint64_t* nonzero_word
  * pinned against the published SipHash-2-4 vector */
 PVW_API int32_t pvw_selftest_siphash(const uint8_t* msg, size_t len, uint64_t k0, uint64_t k1, int32_t c_rounds,
                                      int32_t d_rounds, uint64_t* out);
+/* SELF-TEST (host only, no GPU): the short path of the device gadget decode (decode_scalar_pvw_rns,
+ * src/crypto/decryption.rs:10-247) restated sequentially with the same arithmetic -- candidates confirmed on every limb,
+ * noise_{l-1} proven from the residues, the chain to a fixed point.  short_path[d] (may be NULL) = 1 where every proof
+ * held; elsewhere the value comes from pvw_selftest_decode_fixed's algorithm.  No product path calls it. */
+PVW_API int32_t pvw_selftest_decode_shortcuts(const pvw_ctx* ctx, const uint64_t* noisy, size_t count, uint64_t* out_u64,
+                                              uint8_t* short_path);
 /* SELF-TEST (host only, no GPU): the per-context constants behind the short cuts of the device gadget decode
  * (decode_scalar_pvw_rns, src/crypto/decryption.rs:10-247: mixed-radix inverses and partial products of the leading
  * moduli, the normalised 2*Delta with its reciprocal, Delta^(l-1) mod q_i with its inverses) checked against their

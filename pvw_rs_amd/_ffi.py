@@ -84,6 +84,7 @@ _SIGNATURES = {
     "pvw_selftest_secret_residue": [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "pvw_selftest_siphash": [_P, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)],
     "pvw_selftest_decode_tables": [_P, C.POINTER(C.c_uint32)],
+    "pvw_selftest_decode_shortcuts": [_P, _P, C.c_size_t, _P, _P],
     "pvw_build_is_tuning": [],
     "pvw_crs_seed_from_tag": [C.c_char_p, _P],
     "pvw_ntt_forward": [_P, _P, C.c_size_t],

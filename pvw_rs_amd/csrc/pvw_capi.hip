@@ -1961,6 +1961,98 @@ int32_t pvw_selftest_decode_fixed(const pvw_ctx* c, const uint64_t* noisy, size_
   return PVW_OK;
 }
 
+// SELF-TEST (host only): the short path of decode_chain_kernel restated sequentially with the SAME arithmetic (pvw_decode.h:
+// garner_small, small_chain_step, small_top_*): candidates for every chain input, each confirmed on every limb; noise_{l-1}
+// guessed and proven; the chain as passes to a fixed point; the plaintext from the two small values.  true + *out when every
+// proof holds (the device then never touches its W-word path for this ciphertext); false when any does not (the device
+// settles that part the general way; here the caller takes decode_one_fixed for the whole ciphertext -- same result).
+static bool decode_one_short(const pvw_ctx* c, const u64* noisy, u64* out) {
+  const DecodeTables& t = c->dec_host;
+  const u32 L = t.L, l = t.ell, W = t.W;
+  if (!t.gar_n || !t.sc_on || !t.hs_on || l < 3 || W < 4) return false;
+  auto z = [&](u32 limb, u32 i) -> u64 { return noisy[(size_t)limb * l + i]; };
+  auto res = [&](u32 limb, u32 item) -> u64 {               // tmp_item (decryption.rs:19-27) or z_0 (item == l) on one limb
+    const u64 q = t.mods[limb].q;
+    return item < l ? submod(mulmod_shoup(z(limb, item), t.dmod[limb], t.dmodp[limb], q), z(limb, item + 1), q) : z(limb, 0);
+  };
+  std::vector<u64> cand((size_t)5 * l);
+  for (u32 idx = 0; idx < l; ++idx) {
+    const u32 item = idx + 1 < l ? idx : l;
+    u64 r[4] = {0, 0, 0, 0};
+    for (u32 j = 0; j < t.gar_n; ++j) r[j] = res(j, item);
+    u64* cv = &cand[(size_t)5 * idx];
+    garner_small(t, r, cv);
+    const bool ng = (cv[4] & 1) != 0;
+    for (u32 limb = 0; limb < L; ++limb) {                    // small_confirm
+      const Mod& m = t.mods[limb];
+      const u64* pw = t.pow64 + (size_t)limb * W;
+      u128 sum = (u128)cv[0] * pw[0] + (u128)cv[1] * pw[1];
+      if (cv[2]) sum += (u128)cv[2] * pw[2];
+      if (cv[3]) sum += (u128)cv[3] * pw[3];
+      u64 sres = reduce128((u64)sum, (u64)(sum >> 64), m);
+      if (ng && sres) sres = m.q - sres;
+      if (sres != res(limb, item)) return false;
+    }
+    cv[4] |= 2;
+  }
+  // first pass of the chain: every step on a zero input
+  std::vector<u64> q(l - 1), nq(l - 1);
+  std::vector<char> ng(l - 1), nng(l - 1);
+  const SmallVal zero{0, 0, 0, false};
+  for (u32 i = 0; i + 1 < l; ++i) {
+    bool n;
+    if (!small_chain_step(t.sc, zero, &cand[(size_t)5 * i], q[i], n)) return false;
+    ng[i] = n;
+  }
+  // small_top: the guess and its proof on every limb
+  SmallVal top;
+  if (!small_top_guess(t.sc, &cand[(size_t)5 * (l - 2)], q[l - 2], top)) return false;
+  std::vector<u64> e(L);
+  for (u32 limb = 0; limb < L; ++limb) {
+    const u64* pw = t.pow64 + (size_t)limb * W;
+    e[limb] = small_top_quotient(top, z(limb, 0), z(limb, l - 1), t.dpm[limb], t.dpm[L + limb], t.dpm[2 * L + limb], t.dpm[3 * L + limb],
+                                 pw[0], pw[1], pw[2], t.mods[limb]);
+  }
+  for (u32 limb = 0; limb < L; ++limb)
+    if (small_top_expected(e[0], t.mods[0].q, t.mods[limb]) != e[limb]) return false;
+  // further passes: step i on the previous output of step i + 1 (the top step on the proven noise_{l-1})
+  bool settled = false;
+  for (int pass = 1; pass < 4 && !settled; ++pass) {
+    settled = true;
+    for (u32 i = 0; i + 1 < l; ++i) {
+      const SmallVal a = i + 2 == l ? top : SmallVal{q[i + 1], 0, 0, ng[i + 1] != 0};
+      bool n;
+      if (!small_chain_step(t.sc, a, &cand[(size_t)5 * i], nq[i], n)) return false;
+      nng[i] = n;
+      if (nq[i] != q[i] || nng[i] != ng[i]) settled = false;
+    }
+    q = nq;
+    ng = nng;
+  }
+  if (!settled) return false;
+  // plaintext = -z_0 - noise_0 (:51-53), extract_constant_term_as_u64 (:226-247): both small, so the centred value is the integer
+  const u64* z0 = &cand[(size_t)5 * (l - 1)];
+  BigInt zv = BigInt::from_words(z0, 4);
+  if (z0[4] & 1) zv = -zv;
+  BigInt n0(q[0]);
+  if (ng[0]) n0 = -n0;
+  const BigInt v = -(zv + n0);
+  *out = (v.neg || v.mag.size() > 1) ? 0 : (v.mag.empty() ? 0 : v.mag[0]);
+  return true;
+}
+int32_t pvw_selftest_decode_shortcuts(const pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* out, uint8_t* short_path) {
+  if (!c || ((!noisy || !out) && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  const DecodeTables& t = c->dec_host;
+  std::vector<u64> x(t.W + 1), y(t.W), nres(t.L);
+  for (size_t d = 0; d < count; ++d) {
+    const u64* nz = noisy + d * c->poly();
+    const bool took = decode_one_short(c, nz, out + d);
+    if (!took) out[d] = decode_one_fixed(t, nz, BN{x.data(), 1}, BN{y.data(), 1}, BN{nres.data(), 1});
+    if (short_path) short_path[d] = took ? 1 : 0;
+  }
+  return PVW_OK;
+}
+
 // decode_scalar_pvw_rns on the device, host buffers in and out
 int32_t pvw_decode(pvw_ctx* c, const uint64_t* noisy, size_t count, uint64_t* out) {
   if (!c || ((!noisy || !out) && count)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");

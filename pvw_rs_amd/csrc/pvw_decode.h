@@ -209,6 +209,196 @@ PVW_HD bool lift_centered(const DecodeTables& t, BN x, ResidueFn res) {
   return false;
 }
 
+// ---- arithmetic of the short cuts of the wave-cooperative decode (pvw_decode_wave.h), host + device ----
+// Garner's mixed-radix digits over the first n = gar_n moduli: from the residues r[0..n) of a value to its centred
+// representative modulo P = q_0..q_{n-1}, as four words + sign in out[0..4] (out[4] bit 0 = negative).  A candidate only:
+// it IS the value's centred representative modulo Q exactly when it reproduces the residue on every limb (|v| <= P/2 < Q/2).
+PVW_HD void garner_small(const DecodeTables& t, const u64 (&r)[4], u64* out) {
+  const u32 NL = t.gar_n;
+  const u64* g = t.gar;
+  u64 xm[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (u32 j = 0; j < 4; ++j) {
+    if (j < NL) {
+      const Mod mj = t.mods[j];
+      u64 u = r[j];
+#pragma unroll
+      for (u32 i = 0; i < j; ++i) {
+        u = submod(u, t.gar_close ? (xm[i] >= mj.q ? xm[i] - mj.q : xm[i]) : reduce128(xm[i], 0, mj), mj.q);
+        u = mulmod_shoup(u, g[4 * j + i], g[16 + 4 * j + i], mj.q);
+      }
+      xm[j] = u;
+    }
+  }
+  // v = x_0 + x_1 q_0 + x_2 q_0 q_1 + x_3 q_0 q_1 q_2  < P
+  u64 v0, v1, v2 = 0, v3 = 0;
+  {
+    u128 p = (u128)xm[1] * g[36] + xm[0];
+    v0 = (u64)p;
+    v1 = (u64)(p >> 64);
+  }
+  if (NL > 2) {
+    u128 p = (u128)xm[2] * g[40] + v0;
+    v0 = (u64)p;
+    p = (u128)xm[2] * g[41] + v1 + (u64)(p >> 64);
+    v1 = (u64)p;
+    v2 = (u64)(p >> 64);
+  }
+  if (NL > 3) {
+    u128 p = (u128)xm[3] * g[44] + v0;
+    v0 = (u64)p;
+    p = (u128)xm[3] * g[45] + v1 + (u64)(p >> 64);
+    v1 = (u64)p;
+    p = (u128)xm[3] * g[46] + v2 + (u64)(p >> 64);
+    v2 = (u64)p;
+    v3 = (u64)(p >> 64);
+  }
+  // centre modulo P
+  const u128 vlo = ((u128)v1 << 64) | v0, vhi = ((u128)v3 << 64) | v2;
+  const u128 hlo = ((u128)g[53] << 64) | g[52], hhi = ((u128)g[55] << 64) | g[54];
+  const bool ng = vhi != hhi ? vhi > hhi : vlo > hlo;
+  if (ng) {
+    const u64* P = g + 32 + 4 * NL;
+    const u128 plo = ((u128)P[1] << 64) | P[0], phi = ((u128)P[3] << 64) | P[2];
+    const u128 dlo = plo - vlo, dhi = phi - vhi - (plo < vlo ? 1 : 0);
+    v0 = (u64)dlo; v1 = (u64)(dlo >> 64); v2 = (u64)dhi; v3 = (u64)(dhi >> 64);
+  }
+  out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3; out[4] = ng ? 1 : 0;
+}
+// One step of the chain, noise_i = round((noise_{i+1} - tmp_i) / Delta) (decryption.rs:44-48, :180-207), on noise-sized
+// operands held by ONE LANE: noise_{i+1} = a and tmp_i = the confirmed candidate cb, both below 2^191 in magnitude, so
+// the step is a few dozen word operations (the general step below spends ~20 ballots and lane shifts on W-word integers
+// that are almost all zeros).  With Q >= 2^193 the integer a - b is the centred difference mod Q; round(p / Delta) =
+// sign(p) * floor((2|p| + Delta) / (2 Delta)) as the general step computes it, here by one Knuth step (4 words by 3,
+// one-word quotient, trial digit from the top words by Moeller-Granlund's reciprocal).  Returns false when an operand or
+// the quotient does not fit (q, qneg are then meaningless).
+struct SmallVal {
+  u64 w0, w1, w2;
+  bool neg;
+};
+PVW_HD bool small_chain_step(const u64* sc, const SmallVal& a, const u64* cb, u64& q, bool& qneg) {
+  const u64 b0 = cb[0], b1 = cb[1], b2 = cb[2], b3 = cb[3], bf = cb[4];
+  bool ok = (bf & 2) != 0 && b3 == 0 && (b2 >> 63) == 0 && (a.w2 >> 63) == 0;
+  const bool bneg = (bf & 1) != 0;
+  u64 p0, p1, p2, p3;                                      // |p|, p = a - b
+  bool pneg;
+  if (a.neg != bneg) {
+    u128 s = (u128)a.w0 + b0;
+    p0 = (u64)s;
+    s = (u128)a.w1 + b1 + (u64)(s >> 64);
+    p1 = (u64)s;
+    s = (u128)a.w2 + b2 + (u64)(s >> 64);
+    p2 = (u64)s;
+    p3 = (u64)(s >> 64);
+    pneg = a.neg;
+  } else {
+    const bool age = a.w2 != b2 ? a.w2 > b2 : (a.w1 != b1 ? a.w1 > b1 : a.w0 >= b0);
+    const u64 x0 = age ? a.w0 : b0, x1 = age ? a.w1 : b1, x2 = age ? a.w2 : b2;
+    const u64 y0 = age ? b0 : a.w0, y1 = age ? b1 : a.w1, y2 = age ? b2 : a.w2;
+    const u128 xl = ((u128)x1 << 64) | x0, yl = ((u128)y1 << 64) | y0, dl = xl - yl;
+    p0 = (u64)dl;
+    p1 = (u64)(dl >> 64);
+    p2 = x2 - y2 - (xl < yl ? 1 : 0);
+    p3 = 0;
+    pneg = age ? a.neg : !a.neg;
+  }
+  // 2|p| + Delta
+  u64 n0 = p0 << 1, n1 = (p1 << 1) | (p0 >> 63), n2 = (p2 << 1) | (p1 >> 63), n3 = (p3 << 1) | (p2 >> 63);
+  {
+    u128 s = (u128)n0 + sc[6];
+    n0 = (u64)s;
+    s = (u128)n1 + sc[7] + (u64)(s >> 64);
+    n1 = (u64)s;
+    s = (u128)n2 + sc[8] + (u64)(s >> 64);
+    n2 = (u64)s;
+    n3 += (u64)(s >> 64);
+  }
+  // the shift that normalised the divisor; anything pushed out means a quotient of more than one word
+  const u32 ws = (u32)sc[4], bs = (u32)sc[5];              // wave-uniform
+  u64 m0, m1, m2, m3;
+  if (ws == 0) {
+    m0 = n0; m1 = n1; m2 = n2; m3 = n3;
+  } else if (ws == 1) {
+    ok = ok && n3 == 0;
+    m0 = 0; m1 = n0; m2 = n1; m3 = n2;
+  } else {
+    ok = ok && (n3 | n2) == 0;
+    m0 = 0; m1 = 0; m2 = n0; m3 = n1;
+  }
+  if (bs) {
+    ok = ok && (m3 >> (64 - bs)) == 0;
+    m3 = (m3 << bs) | (m2 >> (64 - bs));
+    m2 = (m2 << bs) | (m1 >> (64 - bs));
+    m1 = (m1 << bs) | (m0 >> (64 - bs));
+    m0 <<= bs;
+  }
+  const u64 d0 = sc[0], d1 = sc[1], d2 = sc[2], v = sc[3];
+  ok = ok && (m3 != d2 ? m3 < d2 : (m2 != d1 ? m2 < d1 : m1 < d0));              // one-word quotient
+  u64 qh = ~0ULL;                                          // trial digit, at most 2 too large (Knuth D3)
+  if (m3 < d2) {
+    const u128 qq = (u128)v * m3 + (((u128)m3 << 64) | m2);
+    u64 q1 = (u64)(qq >> 64) + 1;
+    const u64 q0 = (u64)qq;
+    u64 r = m2 - q1 * d2;
+    if (r > q0) { --q1; r += d2; }
+    if (r >= d2) { ++q1; r -= d2; }
+    qh = q1;
+  }
+  // m - qh * d; below zero: the trial was too large
+  const u128 t0 = (u128)qh * d0, t1 = (u128)qh * d1 + (u64)(t0 >> 64), t2 = (u128)qh * d2 + (u64)(t1 >> 64);
+  const u128 ml = ((u128)m1 << 64) | m0, mh = ((u128)m3 << 64) | m2;
+  const u128 tl = ((u128)(u64)t1 << 64) | (u64)t0;
+  u128 rl = ml - tl;
+  const u128 th_b = t2 + (ml < tl ? 1 : 0);                // t2 <= 2^128 - 2^64: the borrow cannot wrap it
+  bool below = ok && mh < th_b;
+  u128 rh = mh - th_b;
+  const u128 dlw = ((u128)d1 << 64) | d0;
+  for (int fix = 0; fix < 2 && below; ++fix) {
+    --qh;
+    const u128 nl = rl + dlw;
+    const u128 nh = rh + d2 + (nl < rl ? 1 : 0);
+    below = nh >= rh;                                      // no wrap past 2^128: still below zero (d2 + carry > 0)
+    rl = nl;
+    rh = nh;
+  }
+  q = qh;
+  qneg = pneg && qh != 0;
+  return ok && !below;
+}
+// noise_{l-1} without the Horner lift, the parts that are plain arithmetic (pvw_decode_wave.h: small_top has the story).
+// The guess g = b + round(-b/Delta) Delta for b = tmp_{l-2} (cb: its confirmed candidate), qv = |round(-b/Delta)|.
+PVW_HD bool small_top_guess(const u64* sc, const u64* cb, u64 qv, SmallVal& g) {
+  const u64 b0 = cb[0], b1 = cb[1], b2 = cb[2];
+  const bool bneg = (cb[4] & 1) != 0;
+  const u128 t0 = (u128)qv * sc[6], t1 = (u128)qv * sc[7] + (u64)(t0 >> 64), t2 = (u128)qv * sc[8] + (u64)(t1 >> 64);
+  const u128 pl = ((u128)(u64)t1 << 64) | (u64)t0, ph = t2;                  // qv * Delta, 256 bits
+  const u128 bl = ((u128)b1 << 64) | b0, bh = b2;
+  const bool bge = bh != ph ? bh > ph : bl >= pl;
+  const u128 xl = bge ? bl : pl, xh = bge ? bh : ph, yl = bge ? pl : bl, yh = bge ? ph : bh;
+  const u128 gl = xl - yl, gh = xh - yh - (xl < yl ? 1 : 0);
+  if ((u64)(gh >> 63) != 0) return false;                           // |g| must stay below 2^191
+  g.w0 = (u64)gl; g.w1 = (u64)(gl >> 64); g.w2 = (u64)gh;
+  g.neg = (g.w0 | g.w1 | g.w2) != 0 && (bge ? bneg : !bneg);
+  return true;
+}
+// one limb's e_i = (H_i - g_i) * (Delta^(l-1))^-1 mod q, H_i = z_0 Delta^(l-1) - z_{l-1} (the Horner sum telescopes);
+// pw0..2 = 2^(64 w) mod q
+PVW_HD u64 small_top_quotient(const SmallVal& g, u64 z0, u64 zl1, u64 dp, u64 dpp, u64 dpinv, u64 dpinvp, u64 pw0, u64 pw1, u64 pw2, const Mod& m) {
+  const u64 hi = submod(mulmod_shoup(z0, dp, dpp, m.q), zl1, m.q);
+  const u128 gs = (u128)g.w0 * pw0 + (u128)g.w1 * pw1 + (u128)g.w2 * pw2;
+  u64 gi = reduce128((u64)gs, (u64)(gs >> 64), m);
+  if (g.neg && gi) gi = m.q - gi;
+  return mulmod_shoup(submod(hi, gi, m.q), dpinv, dpinvp, m.q);
+}
+// what e_i must be on this limb if limb 0 says e = e0 (centred modulo q_0)
+PVW_HD u64 small_top_expected(u64 e0, u64 q0, const Mod& m) {
+  const bool eneg = e0 > (q0 >> 1);
+  const u64 emag = eneg ? q0 - e0 : e0;
+  u64 want = reduce128(emag, 0, m);
+  if (eneg && want) want = m.q - want;
+  return want;
+}
+
 // decode_scalar_pvw_rns for one ciphertext.  noisy: [L][l] power-basis residues of this dealer.
 // x: (W+1)-word and y: W-word big-integer scratch; nres: L-word scratch (residues of the current noise).
 PVW_HD u64 decode_one_fixed(const DecodeTables& t, const u64* noisy, BN x, BN y, BN nres) {

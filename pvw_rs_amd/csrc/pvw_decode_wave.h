@@ -175,58 +175,17 @@ __device__ __forceinline__ u64 wave_lift_centered(const WaveDecodeCtx& c, u64 re
 //                     caller takes the full lift.  Results are identical either way.
 __device__ __forceinline__ void small_candidates(const WaveDecodeCtx& c, const u64* zs, u32 l, u32 item, u64* park) {
   const DecodeTables& t = c.t;
-  const u32 NL = t.gar_n;
-  const u64* g = t.gar;
-  u64 xm[4] = {0, 0, 0, 0};
+  u64 r[4] = {0, 0, 0, 0};
 #pragma unroll
   for (u32 j = 0; j < 4; ++j) {
-    if (j < NL) {
-      const Mod mj = t.mods[j];
+    if (j < t.gar_n) {
+      const u64 q = t.mods[j].q;
       const u64* z = zs + (size_t)j * l;
       // this input's residue at limb j: tmp_item (decryption.rs:19-27) or z_0 (item == l)
-      u64 u = item < l ? submod(mulmod_shoup(z[item], t.dmod[j], t.dmodp[j], mj.q), z[item + 1], mj.q) : z[0];
-#pragma unroll
-      for (u32 i = 0; i < j; ++i) {
-        u = submod(u, t.gar_close ? (xm[i] >= mj.q ? xm[i] - mj.q : xm[i]) : reduce128(xm[i], 0, mj), mj.q);
-        u = mulmod_shoup(u, g[4 * j + i], g[16 + 4 * j + i], mj.q);
-      }
-      xm[j] = u;
+      r[j] = item < l ? submod(mulmod_shoup(z[item], t.dmod[j], t.dmodp[j], q), z[item + 1], q) : z[0];
     }
   }
-  // v = x_0 + x_1 q_0 + x_2 q_0 q_1 + x_3 q_0 q_1 q_2  < P
-  u64 v0, v1, v2 = 0, v3 = 0;
-  {
-    u128 p = (u128)xm[1] * g[36] + xm[0];
-    v0 = (u64)p;
-    v1 = (u64)(p >> 64);
-  }
-  if (NL > 2) {
-    u128 p = (u128)xm[2] * g[40] + v0;
-    v0 = (u64)p;
-    p = (u128)xm[2] * g[41] + v1 + (u64)(p >> 64);
-    v1 = (u64)p;
-    v2 = (u64)(p >> 64);
-  }
-  if (NL > 3) {
-    u128 p = (u128)xm[3] * g[44] + v0;
-    v0 = (u64)p;
-    p = (u128)xm[3] * g[45] + v1 + (u64)(p >> 64);
-    v1 = (u64)p;
-    p = (u128)xm[3] * g[46] + v2 + (u64)(p >> 64);
-    v2 = (u64)p;
-    v3 = (u64)(p >> 64);
-  }
-  // centre modulo P
-  const u128 vlo = ((u128)v1 << 64) | v0, vhi = ((u128)v3 << 64) | v2;
-  const u128 hlo = ((u128)g[53] << 64) | g[52], hhi = ((u128)g[55] << 64) | g[54];
-  const bool ng = vhi != hhi ? vhi > hhi : vlo > hlo;
-  if (ng) {
-    const u64* P = g + 32 + 4 * NL;
-    const u128 plo = ((u128)P[1] << 64) | P[0], phi = ((u128)P[3] << 64) | P[2];
-    const u128 dlo = plo - vlo, dhi = phi - vhi - (plo < vlo ? 1 : 0);
-    v0 = (u64)dlo; v1 = (u64)(dlo >> 64); v2 = (u64)dhi; v3 = (u64)(dhi >> 64);
-  }
-  park[0] = v0; park[1] = v1; park[2] = v2; park[3] = v3; park[4] = ng ? 1 : 0;
+  garner_small(t, r, park);
 }
 __device__ __forceinline__ bool small_confirm(const WaveDecodeCtx& c, u64 res, u64* park, u64& x) {
   const u32 lane = c.lane;
@@ -245,106 +204,6 @@ __device__ __forceinline__ bool small_confirm(const WaveDecodeCtx& c, u64 res, u
   return true;
 }
 
-// One step of the chain, noise_i = round((noise_{i+1} - tmp_i) / Delta) (decryption.rs:44-48, :180-207), on noise-sized
-// operands held by ONE LANE: noise_{i+1} = a and tmp_i = the confirmed candidate cb, both below 2^191 in magnitude, so
-// the step is a few dozen word operations (the general step below spends ~20 ballots and lane shifts on W-word integers
-// that are almost all zeros).  With Q >= 2^193 the integer a - b is the centred difference mod Q; round(p / Delta) =
-// sign(p) * floor((2|p| + Delta) / (2 Delta)) as the general step computes it, here by one Knuth step (4 words by 3,
-// one-word quotient, trial digit from the top words by Moeller-Granlund's reciprocal).  Returns false when an operand or
-// the quotient does not fit (q, qneg are then meaningless).
-struct SmallVal {
-  u64 w0, w1, w2;
-  bool neg;
-};
-__device__ __forceinline__ bool small_chain_step(const u64* sc, const SmallVal& a, const u64* cb, u64& q, bool& qneg) {
-  const u64 b0 = cb[0], b1 = cb[1], b2 = cb[2], b3 = cb[3], bf = cb[4];
-  bool ok = (bf & 2) != 0 && b3 == 0 && (b2 >> 63) == 0 && (a.w2 >> 63) == 0;
-  const bool bneg = (bf & 1) != 0;
-  u64 p0, p1, p2, p3;                                      // |p|, p = a - b
-  bool pneg;
-  if (a.neg != bneg) {
-    u128 s = (u128)a.w0 + b0;
-    p0 = (u64)s;
-    s = (u128)a.w1 + b1 + (u64)(s >> 64);
-    p1 = (u64)s;
-    s = (u128)a.w2 + b2 + (u64)(s >> 64);
-    p2 = (u64)s;
-    p3 = (u64)(s >> 64);
-    pneg = a.neg;
-  } else {
-    const bool age = a.w2 != b2 ? a.w2 > b2 : (a.w1 != b1 ? a.w1 > b1 : a.w0 >= b0);
-    const u64 x0 = age ? a.w0 : b0, x1 = age ? a.w1 : b1, x2 = age ? a.w2 : b2;
-    const u64 y0 = age ? b0 : a.w0, y1 = age ? b1 : a.w1, y2 = age ? b2 : a.w2;
-    const u128 xl = ((u128)x1 << 64) | x0, yl = ((u128)y1 << 64) | y0, dl = xl - yl;
-    p0 = (u64)dl;
-    p1 = (u64)(dl >> 64);
-    p2 = x2 - y2 - (xl < yl ? 1 : 0);
-    p3 = 0;
-    pneg = age ? a.neg : !a.neg;
-  }
-  // 2|p| + Delta
-  u64 n0 = p0 << 1, n1 = (p1 << 1) | (p0 >> 63), n2 = (p2 << 1) | (p1 >> 63), n3 = (p3 << 1) | (p2 >> 63);
-  {
-    u128 s = (u128)n0 + sc[6];
-    n0 = (u64)s;
-    s = (u128)n1 + sc[7] + (u64)(s >> 64);
-    n1 = (u64)s;
-    s = (u128)n2 + sc[8] + (u64)(s >> 64);
-    n2 = (u64)s;
-    n3 += (u64)(s >> 64);
-  }
-  // the shift that normalised the divisor; anything pushed out means a quotient of more than one word
-  const u32 ws = (u32)sc[4], bs = (u32)sc[5];              // wave-uniform
-  u64 m0, m1, m2, m3;
-  if (ws == 0) {
-    m0 = n0; m1 = n1; m2 = n2; m3 = n3;
-  } else if (ws == 1) {
-    ok = ok && n3 == 0;
-    m0 = 0; m1 = n0; m2 = n1; m3 = n2;
-  } else {
-    ok = ok && (n3 | n2) == 0;
-    m0 = 0; m1 = 0; m2 = n0; m3 = n1;
-  }
-  if (bs) {
-    ok = ok && (m3 >> (64 - bs)) == 0;
-    m3 = (m3 << bs) | (m2 >> (64 - bs));
-    m2 = (m2 << bs) | (m1 >> (64 - bs));
-    m1 = (m1 << bs) | (m0 >> (64 - bs));
-    m0 <<= bs;
-  }
-  const u64 d0 = sc[0], d1 = sc[1], d2 = sc[2], v = sc[3];
-  ok = ok && (m3 != d2 ? m3 < d2 : (m2 != d1 ? m2 < d1 : m1 < d0));              // one-word quotient
-  u64 qh = ~0ULL;                                          // trial digit, at most 2 too large (Knuth D3)
-  if (m3 < d2) {
-    const u128 qq = (u128)v * m3 + (((u128)m3 << 64) | m2);
-    u64 q1 = (u64)(qq >> 64) + 1;
-    const u64 q0 = (u64)qq;
-    u64 r = m2 - q1 * d2;
-    if (r > q0) { --q1; r += d2; }
-    if (r >= d2) { ++q1; r -= d2; }
-    qh = q1;
-  }
-  // m - qh * d; below zero: the trial was too large
-  const u128 t0 = (u128)qh * d0, t1 = (u128)qh * d1 + (u64)(t0 >> 64), t2 = (u128)qh * d2 + (u64)(t1 >> 64);
-  const u128 ml = ((u128)m1 << 64) | m0, mh = ((u128)m3 << 64) | m2;
-  const u128 tl = ((u128)(u64)t1 << 64) | (u64)t0;
-  u128 rl = ml - tl;
-  const u128 th_b = t2 + (ml < tl ? 1 : 0);                // t2 <= 2^128 - 2^64: the borrow cannot wrap it
-  bool below = ok && mh < th_b;
-  u128 rh = mh - th_b;
-  const u128 dlw = ((u128)d1 << 64) | d0;
-  for (int fix = 0; fix < 2 && below; ++fix) {
-    --qh;
-    const u128 nl = rl + dlw;
-    const u128 nh = rh + d2 + (nl < rl ? 1 : 0);
-    below = nh >= rh;                                      // no wrap past 2^128: still below zero (d2 + carry > 0)
-    rl = nl;
-    rh = nh;
-  }
-  q = qh;
-  qneg = pneg && qh != 0;
-  return ok && !below;
-}
 // noise_{l-1} without lifting the Horner value.  The reference lifts H = sum_i tmp_i Delta^(l-2-i) (= z_0 Delta^(l-1) -
 // z_{l-1}, the sum telescopes) to (-Q/2, Q/2] and reduces it modulo Delta^(l-1), centred (decryption.rs:30-37, :154-178):
 // a W-word lift and a W-word division for a result that, in a well-formed ciphertext, is a noise value.  Here: GUESS
@@ -357,36 +216,13 @@ __device__ __forceinline__ bool small_chain_step(const u64* sc, const SmallVal& 
 __device__ __forceinline__ bool small_top(const WaveDecodeCtx& c, const u64* z, const u64* cand, u32 l, u64 qv, SmallVal& top) {
   const DecodeTables& t = c.t;
   const u32 lane = c.lane, L = c.L;
-  const u64* cb = cand + (size_t)(l - 2) * 5;
-  // g = b + round(-b/Delta) * Delta = b - sign(b) qv Delta
-  const u64 b0 = cb[0], b1 = cb[1], b2 = cb[2];
-  const bool bneg = (cb[4] & 1) != 0;
-  const u128 t0 = (u128)qv * t.sc[6], t1 = (u128)qv * t.sc[7] + (u64)(t0 >> 64), t2 = (u128)qv * t.sc[8] + (u64)(t1 >> 64);
-  const u128 pl = ((u128)(u64)t1 << 64) | (u64)t0, ph = t2;                  // qv * Delta, 256 bits
-  const u128 bl = ((u128)b1 << 64) | b0, bh = b2;
-  const bool bge = bh != ph ? bh > ph : bl >= pl;
-  const u128 xl = bge ? bl : pl, xh = bge ? bh : ph, yl = bge ? pl : bl, yh = bge ? ph : bh;
-  const u128 gl = xl - yl, gh = xh - yh - (xl < yl ? 1 : 0);
-  if ((u64)(gh >> 63) != 0) return false;                           // |g| must stay below 2^191
-  const u64 g0 = (u64)gl, g1 = (u64)(gl >> 64), g2 = (u64)gh;
-  const bool gneg = (g0 | g1 | g2) != 0 && (bge ? bneg : !bneg);
-  // every limb: H_i, g_i, e_i
+  if (!small_top_guess(t.sc, cand + (size_t)(l - 2) * 5, qv, top)) return false;
+  // every limb: e_i = (H_i - g_i) / Delta^(l-1) mod q_i; all of them one small e
   const u32 li = c.limb_on ? lane : 0;
-  const u64 q = c.m.q;
-  const u64 hi = submod(mulmod_shoup(z[0], t.dpm[li], t.dpm[L + li], q), z[l - 1], q);
   const u64* pw = c.powL + li;
-  const u128 gs = (u128)g0 * pw[0] + (u128)g1 * pw[64] + (u128)g2 * pw[128];
-  u64 gi = reduce128((u64)gs, (u64)(gs >> 64), c.m);
-  if (gneg && gi) gi = q - gi;
-  const u64 ei = mulmod_shoup(submod(hi, gi, q), t.dpm[2 * L + li], t.dpm[3 * L + li], q);
-  const u64 e0 = readlane_u64(ei, 0), q0 = t.mods[0].q;
-  const bool eneg = e0 > (q0 >> 1);
-  const u64 emag = eneg ? q0 - e0 : e0;
-  u64 want = reduce128(emag, 0, c.m);
-  if (eneg && want) want = q - want;
-  if (__ballot(c.limb_on && want != ei)) return false;
-  top.w0 = g0; top.w1 = g1; top.w2 = g2; top.neg = gneg;
-  return true;
+  const u64 ei = small_top_quotient(top, z[0], z[l - 1], t.dpm[li], t.dpm[L + li], t.dpm[2 * L + li], t.dpm[3 * L + li], pw[0], pw[64], pw[128], c.m);
+  const u64 want = small_top_expected(readlane_u64(ei, 0), t.mods[0].q, c.m);
+  return __ballot(c.limb_on && want != ei) == 0;
 }
 // The whole chain for noise-sized values.  The steps are serial by definition -- noise_i needs noise_{i+1} -- but for
 // a well-formed ciphertext noise_{i+1} is ~2^-100 of tmp_i and moves round((noise_{i+1} - tmp_i)/Delta) only on a

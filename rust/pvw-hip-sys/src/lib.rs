@@ -137,6 +137,7 @@ extern "C" {
     pub fn pvw_selftest_secret_residue(ctx: *mut PvwCtx, nonzero_words: *mut u64, scanned_words: *mut u64) -> i32;
     pub fn pvw_selftest_siphash(msg: *const u8, len: usize, k0: u64, k1: u64, c_rounds: i32, d_rounds: i32, out: *mut u64) -> i32;
     pub fn pvw_selftest_decode_tables(ctx: *const PvwCtx, info_out: *mut u32) -> i32;
+    pub fn pvw_selftest_decode_shortcuts(ctx: *const PvwCtx, noisy: *const u64, count: usize, out_u64: *mut u64, short_path: *mut u8) -> i32;
     pub fn pvw_build_is_tuning() -> i32;
     // ---- ring primitives (fhe-math call sites: change_representation, from_coefficients) ---------
     pub fn pvw_ntt_forward(ctx: *mut PvwCtx, polys: *mut u64, count: usize) -> i32;

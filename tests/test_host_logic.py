@@ -271,3 +271,39 @@ def test_decode_short_cut_tables_hold_their_identities():
         rc = lib.pvw_selftest_decode_tables(p._h, info)
         assert rc == 0, _ffi.last_error()
         assert tuple(info) == want, (l, len(moduli), tuple(info))
+
+
+@pytest.mark.parametrize("l,L,kind", [(8, 17, "bench"), (16, 34, "bench"), (16, 17, "bench"), (8, 12, "mixed"), (8, 3, "test")])
+def test_decode_short_path_restated_on_the_host_matches_the_model(l, L, kind):
+    # The short path of the device decode (candidates from a few residues confirmed on every limb, noise_{l-1} proven from
+    # the residues, the chain to a fixed point) restated sequentially on the host with the very arithmetic the kernel
+    # uses (pvw_selftest_decode_shortcuts): against the big-integer model (decode_scalar_pvw_rns, decryption.rs:10-247)
+    # on inputs on and around every bound those proofs rely on; ciphertext-shaped inputs must have taken the short path,
+    # uniform ones must not have
+    import ctypes as C
+    from _util import decode_cases, primes_1mod
+    from pvw_rs_amd import workloads as W
+    if kind == "bench":
+        moduli = W.bench_moduli(L)
+    elif kind == "mixed":
+        wide, narrow = primes_1mod(64, L // 2), primes_1mod(64, L // 2, top=1 << 40)
+        moduli = [wide[i // 2] if i % 2 == 0 else narrow[i // 2] for i in range(L)]
+    else:
+        moduli = TEST_MODULI
+    p = (P.PvwParametersBuilder().set_parties(3).set_dimension(4).set_l(l).set_moduli(moduli)
+         .set_secret_variance(0.5).set_error_bounds(100, 200).build())
+    m = M.Params(3, 4, l, moduli)
+    cases = decode_cases(l, moduli)
+    arr = np.ascontiguousarray(np.array([[[c % q for c in z] for q in moduli] for z in cases], dtype=np.uint64))
+    out = np.zeros(len(cases), dtype=np.uint64)
+    took = np.zeros(len(cases), dtype=np.uint8)
+    rc = _ffi.lib().pvw_selftest_decode_shortcuts(p._h, arr.ctypes.data_as(C.c_void_p), len(cases), out.ctypes.data_as(C.c_void_p),
+                                                  took.ctypes.data_as(C.c_void_p))
+    assert rc == 0, _ffi.last_error()
+    want = [M.decode_scalar_pvw(z, m) for z in cases]
+    assert [int(x) for x in out] == want
+    if kind == "test":
+        assert not took.any()                       # Q of 109 bits: the chain's short form is off, nothing takes the whole short path
+    else:
+        assert not took[:150].any()                 # the uniform inputs
+        assert took[150:183].all()                  # message * Delta^j + small noise, 33 of them
