@@ -60,6 +60,19 @@ def main():
             k.update({"FETCH_SIZE_KiB_raw": fv, "WRITE_SIZE_KiB": wv, "pmc_launches": cnt,
                       "hbm_traffic_bytes_per_launch": (2.0 * fv + wv) * 1024.0,
                       "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE doubled per the gfx950 correction"})
+    # the bench line the traced process itself printed (its HIP-event timing of the very launches the trace holds)
+    log = os.path.join(os.path.dirname(os.path.normpath(trace_dir)), "trace.log")
+    if os.path.exists(log):
+        for line in open(log, errors="replace"):
+            if line.startswith("{") and '"metric"' in line:
+                try:
+                    j = json.loads(line)
+                    out["traced_process_bench_line"] = {
+                        "ms_per_step": j.get("ms_per_step"), "kernel_ms_per_step": j.get("kernel_ms_per_step"),
+                        "dominant_kernel_avg_launch_us_by_hip_events": j.get("roofline", {}).get("avg_launch_us"),
+                        "note": "same process as the kernel trace above (event timing runs under the tracer here)"}
+                except ValueError:
+                    pass
     with open(os.path.join(root, f"{tag}_summary.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
