@@ -2205,6 +2205,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
       w->events.push_back(e);
     }
   }
+  bool shat_wiped = false;
   auto chunks = [&]() -> int32_t {
   for (size_t i = 0; i < nch; ++i) {
     const size_t d0 = i * chunk, cnt = (D - d0) < chunk ? (D - d0) : chunk;
@@ -2227,7 +2228,11 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
       ntt_domain = false;
     }
     ProfScope ps(c, "decode", ds);
-    PVW_HIP(launch_decode(nz, d_out + d0, cnt, c->dec_dev, ds, ntt_domain ? &c->dt : nullptr));                  // :116, :10-58
+    // one pass on one stream: the decode is the last launch to follow the inner products, and clears NTT(sk) on its way
+    bool by_decode = false;
+    PVW_HIP(launch_decode(nz, d_out + d0, cnt, c->dec_dev, ds, ntt_domain ? &c->dt : nullptr,                    // :116, :10-58
+                          overlap ? nullptr : w->rhat, overlap ? 0 : (size_t)k * P * 8, &by_decode));
+    if (by_decode) shat_wiped = true;
   }
   if (overlap) {
     PVW_HIP(hipEventRecord(w->events[nch], w->aux));
@@ -2240,7 +2245,14 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
     if (w->aux) hipStreamSynchronize(w->aux);
     hipStreamSynchronize(s);
   }
-  int32_t rw = wipe_shat(c, w, s);          // every decrypt_mac launch above is on `s`
+  int32_t rw = PVW_OK;
+  if (rc == PVW_OK && shat_wiped) {         // cleared by the decode launch: recorded as this call's wiped region
+    ws_mark_secret(w, w->rhat, (size_t)k * P * 8);
+    w->wiped = w->secrets;
+    w->secrets.clear();
+  } else {
+    rw = wipe_shat(c, w, s);                // every decrypt_mac launch above is on `s`
+  }
   return rc != PVW_OK ? rc : rw;
 }
 

@@ -33,10 +33,19 @@ __global__ __launch_bounds__(64) void decode_kernel(const u64* __restrict__ nois
 // XF: the residues arrive in the NTT domain and are transformed back while they are staged (stage_inverse).  A separate
 // instance because the compiler gives it 94 registers where the plain one has 79: at most 80 keep the decode co-resident
 // with decrypt_mac_fw, which the overlapped batch path relies on -- that path uses the plain instance behind launch_ntt.
+// wipe / wipe16: a region (16-byte units) the launch clears on its way -- NTT(sk) of the decrypt this decode closes, which every
+// kernel in front of it on the stream has finished reading (the reference's SecretKey is ZeroizeOnDrop; a memset launch of
+// its own cost 4 us + two launch gaps per call).  The grid may hold workgroups beyond `ndec` that do nothing else.
 template <bool XF>
 __global__ __launch_bounds__(512) void decode_chain_kernel(u64* __restrict__ noisy, u64* __restrict__ out,
-                                                            u32 count, u32 cpw_dbg, DecodeTables t, InverseTables xf) {
+                                                            u32 count, u32 cpw_dbg, DecodeTables t, InverseTables xf,
+                                                            u64* __restrict__ wipe, u32 wipe16, u32 ndec) {
   extern __shared__ u64 dws[];
+  if (wipe16) {
+    v2u64* wp = reinterpret_cast<v2u64*>(wipe);
+    for (u32 x = blockIdx.x * 512 + threadIdx.x; x < wipe16; x += gridDim.x * 512) wp[x] = (v2u64){0, 0};
+  }
+  if (blockIdx.x >= ndec) return;
   if (!XF) xf.itw = nullptr;
   decode_chain_body<4>(noisy, out, count, cpw_dbg, t, xf, blockIdx.x, dws);
 }
@@ -60,7 +69,9 @@ static size_t decode_chain_lds(const DecodeTables& t, u32 cpw, u32 wpc) {
   return ((size_t)t.L * t.W + 2 * (2 * t.W + 2) + 256 + (size_t)cpw * ((size_t)(t.ell + 1) * 64 + (size_t)t.L * t.ell + (size_t)5 * t.ell + 2)) * 8;
 }
 
-hipError_t launch_decode(u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s, const DevTables* xf) {
+hipError_t launch_decode(u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s, const DevTables* xf,
+                         u64* wipe, size_t wipe_bytes, bool* wiped) {
+  if (wiped) *wiped = false;
   if (count == 0) return hipSuccess;
   InverseTables inv{nullptr, nullptr, nullptr, nullptr};
   if (xf) inv = InverseTables{xf->itw, xf->itwp, xf->linv, xf->linvp};
@@ -72,12 +83,16 @@ hipError_t launch_decode(u64* noisy, u64* out, size_t count, const DecodeTables&
     const u32 wpc = 4, cpw = 2;
     const size_t bytes = decode_chain_lds(t, cpw, wpc);
     if (bytes <= 160 * 1024) {
-      const dim3 grid((u32)((count + cpw - 1) / cpw)), block(cpw * wpc * 64);
+      const u32 ndec = (u32)((count + cpw - 1) / cpw);
+      const bool do_wipe = wipe && wipe_bytes && wipe_bytes % 16 == 0 && wipe_bytes / 16 < (1ull << 32);
+      const u32 wipe16 = do_wipe ? (u32)(wipe_bytes / 16) : 0;
+      const dim3 grid(do_wipe && ndec < 128 ? 128u : ndec), block(cpw * wpc * 64);      // a small batch gets helpers for the wipe
+      if (wiped) *wiped = do_wipe;
       // tuning build only: PVW_DECODE_TIMING=1..6: out[] = cycles of a phase (results are NOT values; tools/decode_timing.py)
       const u32 dbg = (u32)PVW_ENV_INT("PVW_DECODE_TIMING", 0);
       const u32 no_small = PVW_ENV_INT("PVW_DECODE_SMALL", 1) == 0 ? 1u << 31 : 0;     // tuning build: every lift in full
-      if (xf) decode_chain_kernel<true><<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | ((dbg & 0xff) << 16) | no_small, t, inv);
-      else decode_chain_kernel<false><<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | ((dbg & 0xff) << 16) | no_small, t, inv);
+      if (xf) decode_chain_kernel<true><<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | ((dbg & 0xff) << 16) | no_small, t, inv, wipe, wipe16, ndec);
+      else decode_chain_kernel<false><<<grid, block, bytes, s>>>(noisy, out, (u32)count, cpw | ((dbg & 0xff) << 16) | no_small, t, inv, wipe, wipe16, ndec);
       return hipGetLastError();
     }
   }

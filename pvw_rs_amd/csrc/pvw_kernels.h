@@ -240,6 +240,10 @@ hipError_t launch_mfma_probe(const signed char* A, const signed char* B, int* C,
 // xf == nullptr: noisy holds power-basis polynomials (read only).  xf != nullptr: noisy holds them in the NTT domain; the
 // decode transforms each ciphertext back as it stages it and stores the power-basis polynomial over it (the inverse
 // transform of decrypt, decryption.rs:116, without a launch of its own).
-hipError_t launch_decode(u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s, const DevTables* xf = nullptr);
+// wipe / wipe_bytes (a multiple of 16): a region the decode launch clears as well (NTT(sk) of the decrypt it closes; every
+// launch in front of it on `s` must be done with it); *wiped says whether this launch took that on (the fixed-width
+// fallback does not).
+hipError_t launch_decode(u64* noisy, u64* out, size_t count, const DecodeTables& t, hipStream_t s, const DevTables* xf = nullptr,
+                         u64* wipe = nullptr, size_t wipe_bytes = 0, bool* wiped = nullptr);
 
 }  // namespace pvw
