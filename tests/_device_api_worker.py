@@ -106,6 +106,9 @@ def main():
     P.api._check(lib.pvw_decrypt_batch_device(p._h, ptr(d_sk), ptr(d_c1s), ptr(d_c2col), D, P.REPR_NTT, ptr(d_noisy_b), ptr(d_vals_b), stream))
     torch.cuda.synchronize()
     assert torch.equal(d_noisy_b, d_noisy) and torch.equal(d_vals_b, d_vals)
+    # ... and left nothing of NTT(sk) behind (a single-pass call has its decode launch clear it; secret_key.rs:20-30)
+    nz, scanned = P.api._secret_residue(p)
+    assert nz == 0 and scanned > 0, (nz, scanned)
     graph_capture(lib, dev)
     config5_full_size(lib, stream, dev)
     print("DEVICE_API_OK")
