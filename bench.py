@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--dealers", type=int, default=0,
                     help="encrypt path only: > 0 batches this many dealers per step through pvw_encrypt_multi "
                          "(encrypt_all_party_shares); value is then party-ciphertexts/s")
+    ap.add_argument("--resident-key", action="store_true",
+                    help="decrypt path: the secret key stays on the device in NTT form (pvw_sk_load) instead of being handed "
+                         "over, transformed and wiped on every call")
     ap.add_argument("--no-worst-case", dest="worst_case", action="store_false",
                     help="decrypt path: skip the second measurement on uniform residues")
     ap.add_argument("--path", default="encrypt", choices=["encrypt", "decrypt", "keygen"],
@@ -523,10 +526,13 @@ def bench_decrypt(args, world, rank, local_rank, dev):
     # config 5's one exchange step: every rank ends up with all D x world decoded shares (8 bytes each)
     gathered = torch.zeros(D * world, dtype=torch.int64, device=dev) if DIST_ON else None
 
+    dkey = P.SecretKey.from_coefficients(params, sk.cpu().numpy()).load_device() if args.resident_key else None
+
     def step(which="dealt"):
         # inner products, INTT and gadget decode on the device: only D x u64 would leave the GPU
         a, b = inputs[which]
-        rc = lib.pvw_decrypt_batch_device(h, C.c_void_p(sk.data_ptr()), C.c_void_p(a.data_ptr()),
+        fn = lib.pvw_decrypt_batch_device_sk if dkey else lib.pvw_decrypt_batch_device
+        rc = fn(h, dkey._h if dkey else C.c_void_p(sk.data_ptr()), C.c_void_p(a.data_ptr()),
                                           C.c_void_p(b.data_ptr()), D, P.REPR_NTT,
                                           C.c_void_p(noisy.data_ptr()), C.c_void_p(vals_dev.data_ptr()), stream)
         if rc != 0:
@@ -605,7 +611,8 @@ def bench_decrypt(args, world, rank, local_rank, dev):
         "config": {"workload": desc, "dealers_per_gpu": D, "k": k, "l": l, "rns_limbs": L,
                    "q_bits": int(params.q_total().bit_length()),
                    "sharding": f"dealer-sharded x{world}" + (", all-gather of D x u64 decoded shares per step" if DIST_ON else ""),
-                   "world_size_observed": world, "backend": (os.environ.get("PVW_BENCH_BACKEND", "nccl") if DIST_ON else None)},
+                   "world_size_observed": world, "backend": (os.environ.get("PVW_BENCH_BACKEND", "nccl") if DIST_ON else None),
+                   "secret_key": "resident on the device in NTT form (pvw_sk_load)" if dkey else "coefficients handed over, transformed and wiped per call"},
         "roofline": {"bound": "hbm", "kernel": "decrypt_mac_fw_kernel" if L * l // 2 >= 128 else "decrypt_mac_grouped_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6, "launches_timed": launches,

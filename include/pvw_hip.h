@@ -245,6 +245,18 @@ PVW_API int32_t pvw_decrypt_noisy_device(pvw_ctx* ctx, const int64_t* d_sk, cons
 PVW_API int32_t pvw_decrypt_batch_device(pvw_ctx* ctx, const int64_t* d_sk, const uint64_t* d_c1s,
                                  const uint64_t* d_c2col, size_t num_dealers, uint32_t in_repr,
                                  uint64_t* d_noisy, uint64_t* d_out, void* stream);
+/* A secret key kept on the device as the inner products read it -- NTT(sk[j]) in the ciphertext layout, what
+ * SecretKey::get_polynomial computes k times per decrypt_party_value (src/keys/secret_key.rs:98-112, called at
+ * src/crypto/decryption.rs:260).  decrypt_party_shares (decryption.rs:281-325) decrypts n ciphertexts under ONE key: load it
+ * once, decrypt with pvw_decrypt_batch_device_sk as often as needed (no transform of the key, no wipe per call), free it when
+ * the SecretKey is dropped -- pvw_sk_free clears the device copy (Zeroize + ZeroizeOnDrop, secret_key.rs:20-30).
+ * sk: k x l coefficients on the host.  The handle belongs to `ctx` and must be freed before it. */
+typedef struct pvw_sk pvw_sk;
+PVW_API int32_t pvw_sk_load(pvw_ctx* ctx, const int64_t* sk /*[k][l]*/, pvw_sk** out);
+PVW_API int32_t pvw_sk_free(pvw_sk* key);
+PVW_API int32_t pvw_decrypt_batch_device_sk(pvw_ctx* ctx, const pvw_sk* key, const uint64_t* d_c1s,
+                                            const uint64_t* d_c2col, size_t num_dealers, uint32_t in_repr,
+                                            uint64_t* d_noisy, uint64_t* d_out, void* stream);
 /* decode_scalar_pvw_rns alone, on the device: noisy [D][L][l] power basis (host) -> out_u64 [D] */
 PVW_API int32_t pvw_decode(pvw_ctx* ctx, const uint64_t* noisy, size_t count, uint64_t* out_u64);
 /* the same with host big integers on the host cores (no GPU needed): an independent

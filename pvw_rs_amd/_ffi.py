@@ -76,6 +76,9 @@ _SIGNATURES = {
     "pvw_decrypt_batch": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P],
     "pvw_decrypt_noisy_device": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P],
     "pvw_decrypt_batch_device": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P, _P],
+    "pvw_sk_load": [_P, _P, C.POINTER(C.c_void_p)],
+    "pvw_sk_free": [_P],
+    "pvw_decrypt_batch_device_sk": [_P, _P, _P, _P, C.c_size_t, C.c_uint32, _P, _P, _P],
     "pvw_decode": [_P, _P, C.c_size_t, _P],
     "pvw_decode_host": [_P, _P, C.c_size_t, _P],
     "pvw_decode_device": [_P, _P, C.c_size_t, _P, _P],

@@ -421,6 +421,11 @@ class SecretKey:
         except Exception:
             pass
 
+    def load_device(self) -> "DeviceSecretKey":
+        """The key in the form the inner products of decrypt read (NTT(sk[j]), secret_key.rs:98-112), resident on the
+        device until the returned handle is freed: pvw_decrypt_batch_device_sk then neither transforms nor wipes per call."""
+        return DeviceSecretKey(self)
+
     def get_polynomial(self, index: int) -> np.ndarray:                   # :98-112 (NTT form)
         if not 0 <= index < len(self.secret_coeffs):
             raise PvwError(1, f"Index {index} out of bounds for {len(self.secret_coeffs)} polynomials")
@@ -670,6 +675,35 @@ def decrypt_party_shares(all_ciphertexts: Sequence[PvwCiphertext], secret_key: S
         except PvwError as e:
             raise PvwError(1, f"Ciphertext {d} invalid: {e}")
     return _decrypt_batch(p, all_ciphertexts, secret_key, party_index, return_noisy)
+
+
+class DeviceSecretKey:
+    """pvw_sk: a SecretKey's NTT form on the device (pvw_sk_load); cleared by free() / on drop (pvw_sk_free), as the
+    reference's SecretKey is ZeroizeOnDrop (secret_key.rs:20-30).  Use as a context manager or call free()."""
+
+    def __init__(self, secret_key: SecretKey):
+        self.params = secret_key.params
+        h = C.c_void_p()
+        sk = _i64(secret_key.secret_coeffs)
+        self.params._call("pvw_sk_load", _ptr(sk), C.byref(h))
+        self._h = h
+
+    def free(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _check(_ffi.lib().pvw_sk_free(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def _decrypt_batch(p, cts, secret_key, party_index, return_noisy=False):

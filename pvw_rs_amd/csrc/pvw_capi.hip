@@ -2093,7 +2093,8 @@ int32_t pvw_decode_device(pvw_ctx* c, const uint64_t* d_noisy, size_t count, uin
 // the pass that adds them up (decrypt_finish) does it; without, the consumer does -- the decode kernel itself
 // (launch_decode with the transform tables) or launch_ntt.
 static int32_t decrypt_mac_only(pvw_ctx* c, Workspace* w, const u64* d_c1s, const u64* d_c2col, size_t D, u64* d_noisy,
-                                hipStream_t s, bool* ntt_domain, bool alone = true) {
+                                hipStream_t s, bool* ntt_domain, bool alone = true, const u64* shat = nullptr) {
+  if (!shat) shat = w->rhat;                           // NTT(sk) made by this call (launch_prep); else a resident key's
   const u32 k = c->k, l = c->l, L = c->L;
   const u32 ns = decrypt_split(k, L, l, D);
   if (ns > 1) {
@@ -2106,7 +2107,7 @@ static int32_t decrypt_mac_only(pvw_ctx* c, Workspace* w, const u64* d_c1s, cons
   }
   {
     ProfScope ps(c, "decrypt_mac", s);
-    PVW_HIP(launch_decrypt_mac(d_c1s, w->rhat, d_c2col, d_noisy, c->dt, k, L, l, D, s, w->dpart, ns, alone));
+    PVW_HIP(launch_decrypt_mac(d_c1s, shat, d_c2col, d_noisy, c->dt, k, L, l, D, s, w->dpart, ns, alone));
   }
   *ntt_domain = ns <= 1;
   if (ns > 1) {
@@ -2171,9 +2172,69 @@ int32_t pvw_decrypt_noisy_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
 // ciphertexts; only D x u64 are produced.  Large batches are cut into chunks of about 2 GiB and the
 // decode of chunk i (integer-ALU work, a few waves per CU) runs on a helper stream under the HBM-bound MAC of
 // chunk i+1; the caller's stream waits for the last decode before the call's work counts as complete.
+// A secret key kept on the device in the form the inner products read (NTT(sk[j]) in the ciphertext layout,
+// secret_key.rs:98-112): decrypt calls that take one skip the transform of the key and the wipe behind it.  The reference's
+// SecretKey lives as long as its owner does and is ZeroizeOnDrop (secret_key.rs:20-30); so does this: pvw_sk_free clears it.
+struct pvw_sk {
+  pvw_ctx* ctx;
+  u64* shat;       // [k][L][l]
+  size_t bytes;
+};
+static int32_t decrypt_batch_core(pvw_ctx* c, const int64_t* d_sk, const u64* key_shat, const uint64_t* d_c1s, const uint64_t* d_c2col,
+                                  size_t D, uint32_t in_repr, uint64_t* d_noisy, uint64_t* d_out, void* stream);
 int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t* d_c1s, const uint64_t* d_c2col,
                                  size_t D, uint32_t in_repr, uint64_t* d_noisy, uint64_t* d_out, void* stream) {
-  if (!c || !d_sk || ((!d_c1s || !d_c2col || !d_noisy || !d_out) && D)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (!c || !d_sk) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  return decrypt_batch_core(c, d_sk, nullptr, d_c1s, d_c2col, D, in_repr, d_noisy, d_out, stream);
+}
+int32_t pvw_decrypt_batch_device_sk(pvw_ctx* c, const pvw_sk* key, const uint64_t* d_c1s, const uint64_t* d_c2col,
+                                    size_t D, uint32_t in_repr, uint64_t* d_noisy, uint64_t* d_out, void* stream) {
+  if (!c || !key || !key->shat) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  if (key->ctx != c) return fail(PVW_ERR_INVALID_PARAMETERS, "the key was loaded for another context");
+  return decrypt_batch_core(c, nullptr, key->shat, d_c1s, d_c2col, D, in_repr, d_noisy, d_out, stream);
+}
+int32_t pvw_sk_load(pvw_ctx* c, const int64_t* sk, pvw_sk** out) {
+  if (!c || !sk || !out) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
+  *out = nullptr;
+  PVW_TRY(ensure_device(c));
+  const size_t k = c->k, l = c->l, P = c->poly();
+  pvw_sk* key = new pvw_sk{c, nullptr, k * P * 8};
+  i64* stage = nullptr;
+  hipError_t e = hipMalloc((void**)&key->shat, key->bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&stage, k * l * 8);
+  if (e == hipSuccess) e = hipMemcpyAsync(stage, sk, k * l * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_prep(stage, nullptr, key->shat, P, l, (u32)k, true, c->dt, c->L, c->l, c->stream);
+  if (stage) {                                               // the uploaded coefficients do not outlive the call
+    hipError_t e2 = hipMemsetAsync(stage, 0, k * l * 8, c->stream);
+    if (e == hipSuccess) e = e2;
+  }
+  hipError_t e3 = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = e3;
+  if (stage) hipFree(stage);
+  if (e != hipSuccess) {
+    if (key->shat) { hipMemset(key->shat, 0, key->bytes); hipFree(key->shat); }
+    delete key;
+    (void)hipGetLastError();
+    return fail(PVW_ERR_INTERNAL, "loading the secret key failed");
+  }
+  *out = key;
+  return PVW_OK;
+}
+int32_t pvw_sk_free(pvw_sk* key) {
+  if (!key) return PVW_OK;
+  int32_t rc = PVW_OK;
+  if (key->shat) {
+    if (key->ctx) (void)hipSetDevice(key->ctx->device);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(key->shat, 0, key->bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+      rc = fail(PVW_ERR_INTERNAL, "clearing the secret key failed");
+    hipFree(key->shat);
+  }
+  delete key;
+  return rc;
+}
+static int32_t decrypt_batch_core(pvw_ctx* c, const int64_t* d_sk, const u64* key_shat, const uint64_t* d_c1s, const uint64_t* d_c2col,
+                                  size_t D, uint32_t in_repr, uint64_t* d_noisy, uint64_t* d_out, void* stream) {
+  if (!c || ((!d_c1s || !d_c2col || !d_noisy || !d_out) && D)) return fail(PVW_ERR_INVALID_PARAMETERS, "NULL argument");
   PVW_TRY(check_repr(in_repr));
   if (in_repr != PVW_REPR_NTT) return fail(PVW_ERR_INVALID_FORMAT, "device decrypt takes NTT-domain ciphertexts");
   if (D == 0) return fail(PVW_ERR_INVALID_PARAMETERS, "No ciphertexts provided");          // decryption.rs:286-290
@@ -2192,7 +2253,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
   if (chunk_env >= 64) chunk = (size_t)chunk_env;
   else if (total_gib >= 3.0) chunk = (D + (size_t)(total_gib / 2.0) - 1) / (size_t)(total_gib / 2.0);
   const size_t nch = (D + chunk - 1) / chunk;
-  {
+  if (!key_shat) {
     ProfScope ps(c, "prep", s);
     PVW_HIP(launch_prep(d_sk, nullptr, w->rhat, P, l, k, true, c->dt, L, l, s));   // NTT(sk[j]) once per call (secret_key.rs:98-112)
   }
@@ -2211,7 +2272,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
     const size_t d0 = i * chunk, cnt = (D - d0) < chunk ? (D - d0) : chunk;
     u64* nz = d_noisy + d0 * P;
     bool ntt_domain = false;
-    PVW_TRY(decrypt_mac_only(c, w, d_c1s + d0 * k * P, d_c2col + d0 * P, cnt, nz, s, &ntt_domain, !overlap));   // decryption.rs:257-274
+    PVW_TRY(decrypt_mac_only(c, w, d_c1s + d0 * k * P, d_c2col + d0 * P, cnt, nz, s, &ntt_domain, !overlap, key_shat));   // decryption.rs:257-274
     hipStream_t ds = s;
     if (overlap) {
       PVW_HIP(hipEventRecord(w->events[i], s));
@@ -2231,7 +2292,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
     // one pass on one stream: the decode is the last launch to follow the inner products, and clears NTT(sk) on its way
     bool by_decode = false;
     PVW_HIP(launch_decode(nz, d_out + d0, cnt, c->dec_dev, ds, ntt_domain ? &c->dt : nullptr,                    // :116, :10-58
-                          overlap ? nullptr : w->rhat, overlap ? 0 : (size_t)k * P * 8, &by_decode));
+                          overlap || key_shat ? nullptr : w->rhat, overlap || key_shat ? 0 : (size_t)k * P * 8, &by_decode));
     if (by_decode) shat_wiped = true;
   }
   if (overlap) {
@@ -2246,6 +2307,7 @@ int32_t pvw_decrypt_batch_device(pvw_ctx* c, const int64_t* d_sk, const uint64_t
     hipStreamSynchronize(s);
   }
   int32_t rw = PVW_OK;
+  if (key_shat) return rc;                  // a resident key: nothing of it was copied anywhere
   if (rc == PVW_OK && shat_wiped) {         // cleared by the decode launch: recorded as this call's wiped region
     ws_mark_secret(w, w->rhat, (size_t)k * P * 8);
     w->wiped = w->secrets;

@@ -19,6 +19,12 @@ pub struct PvwCtx {
     _private: [u8; 0],
 }
 
+/// Opaque device-resident secret key (`pvw_sk` in the header): NTT(sk) as the inner products of decrypt read it.
+#[repr(C)]
+pub struct PvwSk {
+    _private: [u8; 0],
+}
+
 /// `pvw_params_t`: the `PvwParametersBuilder` fields (`src/params/parameters.rs:44-52`) plus device placement.
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
@@ -128,6 +134,9 @@ extern "C" {
     pub fn pvw_decrypt_batch(ctx: *mut PvwCtx, sk: *const i64, c1s: *const u64, c2col: *const u64, num_dealers: usize, in_repr: u32, out_u64: *mut u64, noisy_out: *mut u64) -> i32;
     pub fn pvw_decrypt_noisy_device(ctx: *mut PvwCtx, d_sk: *const i64, d_c1s: *const u64, d_c2col: *const u64, num_dealers: usize, in_repr: u32, d_noisy: *mut u64, stream: *mut c_void) -> i32;
     pub fn pvw_decrypt_batch_device(ctx: *mut PvwCtx, d_sk: *const i64, d_c1s: *const u64, d_c2col: *const u64, num_dealers: usize, in_repr: u32, d_noisy: *mut u64, d_out: *mut u64, stream: *mut c_void) -> i32;
+    pub fn pvw_sk_load(ctx: *mut PvwCtx, sk: *const i64, out: *mut *mut PvwSk) -> i32;
+    pub fn pvw_sk_free(key: *mut PvwSk) -> i32;
+    pub fn pvw_decrypt_batch_device_sk(ctx: *mut PvwCtx, key: *const PvwSk, d_c1s: *const u64, d_c2col: *const u64, num_dealers: usize, in_repr: u32, d_noisy: *mut u64, d_out: *mut u64, stream: *mut c_void) -> i32;
     pub fn pvw_decode(ctx: *mut PvwCtx, noisy: *const u64, count: usize, out_u64: *mut u64) -> i32;
     pub fn pvw_decode_host(ctx: *const PvwCtx, noisy: *const u64, count: usize, out_u64: *mut u64) -> i32;
     pub fn pvw_decode_device(ctx: *mut PvwCtx, d_noisy: *const u64, count: usize, d_out: *mut u64, stream: *mut c_void) -> i32;

@@ -102,6 +102,39 @@ fn flat_secret(sk: &SecretKey) -> Vec<i64> {
     sk.secret_coeffs.iter().flat_map(|row| row.iter().copied()).collect()
 }
 
+/// A `SecretKey` kept on the device in the form the inner products of decrypt read (`pvw_sk_load`: NTT(sk[j]), what
+/// `SecretKey::get_polynomial` computes k times per `decrypt_party_value`, secret_key.rs:98-112 / decryption.rs:260).  For a
+/// receiver that decrypts many device-resident ciphertext batches under one key: `pvw_decrypt_batch_device_sk` then neither
+/// transforms nor wipes per call.  Dropping the handle clears the device copy (`pvw_sk_free`), as dropping the reference's
+/// `SecretKey` zeroizes it (secret_key.rs:20-30).  Must not outlive the `PvwParameters` it was loaded for.
+pub struct DeviceSecretKey {
+    raw: *mut sys::PvwSk,
+}
+
+impl DeviceSecretKey {
+    pub fn load(secret_key: &SecretKey) -> Result<Self> {
+        let mut sk = flat_secret(secret_key);
+        let mut raw: *mut sys::PvwSk = std::ptr::null_mut();
+        let rc = unsafe { sys::pvw_sk_load(secret_key.params.hip.raw(), sk.as_ptr(), &mut raw) };
+        sk.zeroize();
+        check(rc)?;
+        Ok(Self { raw })
+    }
+
+    pub fn raw(&self) -> *const sys::PvwSk {
+        self.raw
+    }
+}
+
+impl Drop for DeviceSecretKey {
+    fn drop(&mut self) {
+        if !self.raw.is_null() {
+            unsafe { sys::pvw_sk_free(self.raw) };
+            self.raw = std::ptr::null_mut();
+        }
+    }
+}
+
 /// `decrypt_party_value` (decryption.rs:249-278): <sk, c1> - c2[party_index], inverse NTT and the gadget decode
 /// (`decode_scalar_pvw_rns`, :10-58) all on the device; one u64 comes back.
 pub fn decrypt_party_value(ciphertext: &PvwCiphertext, secret_key: &SecretKey, party_index: usize) -> Result<u64> {

@@ -109,6 +109,14 @@ def main():
     # ... and left nothing of NTT(sk) behind (a single-pass call has its decode launch clear it; secret_key.rs:20-30)
     nz, scanned = P.api._secret_residue(p)
     assert nz == 0 and scanned > 0, (nz, scanned)
+    # ... and with the key resident on the device (pvw_sk_load): the same values, nothing transformed or wiped per call
+    with P.SecretKey.from_coefficients(p, sk).load_device() as dkey:
+        for _ in range(2):
+            d_noisy_c = torch.zeros_like(d_noisy)
+            d_vals_c = torch.zeros_like(d_vals)
+            P.api._check(lib.pvw_decrypt_batch_device_sk(p._h, dkey._h, ptr(d_c1s), ptr(d_c2col), D, P.REPR_NTT, ptr(d_noisy_c), ptr(d_vals_c), stream))
+            torch.cuda.synchronize()
+            assert torch.equal(d_noisy_c, d_noisy) and torch.equal(d_vals_c, d_vals)
     graph_capture(lib, dev)
     config5_full_size(lib, stream, dev)
     print("DEVICE_API_OK")

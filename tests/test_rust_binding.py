@@ -18,6 +18,7 @@ C_TO_RUST = {
     "int64_t": "i64", "int64_t*": "*mut i64", "const int64_t*": "*const i64",
     "float": "f32", "double*": "*mut f64", "void*": "*mut c_void", "void**": "*mut *mut c_void",
     "pvw_ctx*": "*mut PvwCtx", "const pvw_ctx*": "*const PvwCtx", "pvw_ctx**": "*mut *mut PvwCtx",
+    "pvw_sk*": "*mut PvwSk", "const pvw_sk*": "*const PvwSk", "pvw_sk**": "*mut *mut PvwSk",
     "const pvw_params_t*": "*const PvwParamsT", "const pvw_randomness_t*": "*const PvwRandomnessT",
 }
 
