@@ -213,6 +213,23 @@ class SecretKey {
   size_t len() const { return params->k; }
 };
 
+// A SecretKey kept on the device in the form the inner products of decrypt read (pvw_sk_load: NTT(sk[j]),
+// secret_key.rs:98-112) for pvw_decrypt_batch_device_sk; cleared when the handle goes (pvw_sk_free), as the reference's
+// SecretKey is ZeroizeOnDrop (secret_key.rs:20-30).  Keeps its parameters alive.
+class DeviceSecretKey {
+ public:
+  explicit DeviceSecretKey(const SecretKey& sk) : params_(sk.params) { check(pvw_sk_load(params_->ctx, sk.secret_coeffs.data(), &key_)); }
+  DeviceSecretKey(const DeviceSecretKey&) = delete;
+  DeviceSecretKey& operator=(const DeviceSecretKey&) = delete;
+  DeviceSecretKey(DeviceSecretKey&& o) noexcept : params_(std::move(o.params_)), key_(o.key_) { o.key_ = nullptr; }
+  ~DeviceSecretKey() { if (key_) pvw_sk_free(key_); }
+  const pvw_sk* raw() const { return key_; }
+
+ private:
+  std::shared_ptr<PvwParameters> params_;
+  pvw_sk* key_ = nullptr;
+};
+
 // Party (src/keys/public_key.rs:17-22)
 class Party {
  public:
