@@ -681,13 +681,14 @@ def digit_gemm_extreme_case(n, k, l, moduli, D):
         assert np.array_equal(many[d].c2, c2o), f"c2 dealer {d}"
 
 
-def test_digit_gemm_repeats_are_bit_identical():
+@pytest.mark.parametrize("moduli", [M.bench_moduli(3), EXAMPLE_MODULI[:3]], ids=["61-bit: 8-byte contraction", "56-bit: 7-byte contraction"])
+def test_digit_gemm_repeats_are_bit_identical(moduli):
     # The wide digit GEMM keeps LDS-DMA stages in flight across raw barriers (two wave groups half a stage apart): a
     # misplaced wait would show as a rare wrong tile, not as a wrong algorithm.  Same call 40 times, every result
     # equal to the first (tools/gemm_stress.py runs 2000 repeats at the bench sizes); the first is checked against
     # the oracle by the tests above.
-    n, k, l, L, D = 600, 256, 8, 3, 40
-    p = build_params(n, k, l, M.bench_moduli(L))
+    n, k, l, D = 600, 256, 8, 40
+    p = build_params(n, k, l, moduli)
     gpk = P.GlobalPublicKey.new(P.PvwCrs.new_deterministic(p, SEED))
     gpk.fill_uniform(SEED)
     rows = [[(d * 7919 + j) for j in range(n)] for d in range(D)]
