@@ -4,13 +4,13 @@
 out=gpurun_out/dec_sweep.log; : > $out
 run() {
   echo "cfg $1 variant $2 c $3" >> $out
-  PVW_DEC_VARIANT=$2 PVW_DEC_C=$3 timeout -k 10 200 python bench.py --tuning-library --path decrypt --config $1 --steps 30 --warmup 5 2>/dev/null | python -c "
+  PVW_DEC_VARIANT=$2 PVW_DEC_C=$3 timeout -k 10 200 python bench.py --tuning-library --path decrypt --config $1 --steps 30 --warmup 5 --no-worst-case 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print('  ms_per_step',round(d['ms_per_step'],4),'mac_us',round(d['roofline']['avg_launch_us'],1),'GB/s',round(d['roofline']['achieved']))
 " >> $out || exit 1
 }
-for v in 60 61 62 63 64; do for c in 1 2 3; do run c5shard $v $c; done; done
-for c in 4 5 7 10 15; do run d3 10 $c; run d3 11 $c; done
-for v in 30; do for c in 3 7 15; do run d3 $v $c; done; done
+# 60 = full-width form where the shape allows (config 5), 10 = dealer-grouped form; c = replicas over j (0 = by shape)
+for v in 60 10; do for c in 0 1 2 3; do run c5shard $v $c; done; done
+for c in 0 3 4 5 7; do run d3 10 $c; done
