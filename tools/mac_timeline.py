@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-workgroup timeline of one mac_rows launch (tuning build; run on the GPU box):
-    python tools/mac_timeline.py [config] [variant 40|41]
+    python tools/mac_timeline.py [config] [variant 40|44]      (40: the unpacked kernel, 44: the packed stream)
 Every workgroup stamps its first and last instruction (100 MHz counter); this prints the launch span, the ramp
 (first start -> all slots busy), the drain (queue empty -> last end), the workgroup-duration distribution and the
 number of resident workgroups over time."""
@@ -88,33 +88,3 @@ for x in range(8):
     if sel.any():
         print(f"XCD {x}: {int(sel.sum())} items, first start {start[sel].min():.1f}, last start {start[sel].max():.1f}, "
               f"last end {end[sel].max():.1f} us, median duration {np.median(dur[sel]):.1f} us")
-if variant in ("42", "43"):
-    nwg = int((hw & 0x0FFFFFFF).max()) + 1
-    ws = np.zeros((nwg, 2), dtype=np.uint64)
-    p._call("pvw_tuning_read_wg_stamps", ws.ctypes.data_as(C.c_void_p), nwg)
-    entry = (ws[:, 0].astype(np.int64) - t0) / 100.0
-    hwid = ws[:, 1]
-    cu = ((hwid >> 8) & 0xF).astype(np.int64) + 16 * ((hwid >> 13) & 0x7).astype(np.int64) + 128 * ((hwid >> 32) & 0xF).astype(np.int64)
-    print(f"kernel entry of the {nwg} workgroups: min {entry.min():.2f} median {np.median(entry):.2f} p90 {np.percentile(entry, 90):.2f} max {entry.max():.2f} us")
-    first_item_start = np.full(nwg, np.nan)
-    wgid = (hw & 0x0FFFFFFF).astype(np.int64)
-    for w_ in range(nwg):
-        sel = wgid == w_
-        if sel.any():
-            first_item_start[w_] = start[sel].min()
-    lag = first_item_start - entry
-    print(f"entry -> first item start: median {np.nanmedian(lag):.2f} p90 {np.nanpercentile(lag, 90):.2f} max {np.nanmax(lag):.2f} us")
-    late = entry > 3.0
-    print(f"workgroups entering later than 3 us: {int(late.sum())}; distinct (xcc,se,cu) ids overall {len(set(cu.tolist()))}, among late {len(set(cu[late].tolist()))}")
-    wg = hw & 0x0FFFFFFF
-    per = np.bincount(wg)
-    print(f"persistent form: {len(per)} workgroups, items per workgroup min {per.min()} median {int(np.median(per))} max {per.max()}")
-    gaps = []
-    for w in range(0, len(per), max(1, len(per) // 64)):
-        idx = np.where(wg == w)[0]
-        o = idx[np.argsort(start[idx])]
-        gaps += list(start[o][1:] - end[o][:-1])
-    print(f"gap between consecutive items of a workgroup: median {np.median(gaps):.2f} us, p90 {np.percentile(gaps, 90):.2f} us")
-bytes_wg = k * 1024
-print(f"per-workgroup rate while resident: median {bytes_wg / np.median(dur) / 1e3:.2f} GB/s; "
-      f"aggregate at peak residency {peak * bytes_wg / np.median(dur) / 1e6:.2f} TB/s")
